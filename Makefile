@@ -1,0 +1,24 @@
+# Top-level build: the product library (hipcc, gfx950) and the test-only oracle.
+#   make            -> detex_amd/lib/libdetexhip.so  +  oracle/ checkers
+#   make lib        -> only the product library
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := detex_amd/csrc
+LIB   := detex_amd/lib/libdetexhip.so
+HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
+
+all: lib oracle
+lib: $(LIB)
+
+$(LIB): $(CSRC)/detexhip.hip $(HDRS)
+	@mkdir -p detex_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
+		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all lib oracle clean

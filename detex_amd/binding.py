@@ -1,0 +1,130 @@
+"""ctypes binding of libdetexhip.so (include/detex.h + include/detexhip.h) plus torch plumbing.
+
+torch is used only for what the task allows it for: device memory, streams and
+torch.distributed.  Every decode goes through the C ABI into the HIP kernels; there is no
+Python or CPU decode path here, and loading fails loudly if the built library is missing.
+"""
+import ctypes
+import os
+
+from . import formats as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdetexhip.so")
+_lib = None
+
+_vp = ctypes.c_void_p
+
+
+class DetexHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load detex_amd/lib/libdetexhip.so (built by `make lib` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        # torch's wheel bundles its own libamdhip64 (soname libamdhip64.so.7, requested by torch as
+        # "libamdhip64.so"): it must be the first HIP runtime in the process, or torch would load a
+        # second copy next to the /opt/rocm one libdetexhip.so pulls in and see no devices.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise DetexHipError(
+            "%s not found: build it with `make lib` (hipcc --offload-arch=gfx950). "
+            "detex_amd has no fallback decode path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.detexGetErrorMessage.restype = ctypes.c_char_p
+    lib.detexhipVersion.restype = ctypes.c_char_p
+    lib.detexhipKernelName.restype = ctypes.c_char_p
+    lib.detexhipKernelName.argtypes = [ctypes.c_uint32]
+    lib.detexhipSetDevice.argtypes = [ctypes.c_int]
+    lib.detexhipSetKernelVariant.argtypes = [ctypes.c_int]
+    lib.detexhipDecompressTextureLinearDevice.argtypes = [
+        ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t,
+        ctypes.c_uint32, _vp, _vp]
+    lib.detexhipDecompressTextureTiledDevice.argtypes = [
+        ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_uint32, _vp, _vp]
+    lib.detexhipDecompressBlocksDevice.argtypes = [
+        ctypes.c_uint32, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    m = load().detexGetErrorMessage()
+    return None if m is None else m.decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DetexHipError("%s failed: %s" % (what, last_error()))
+
+
+def set_kernel_variant(v):
+    load().detexhipSetKernelVariant(int(v))
+
+
+def kernel_name(fmt):
+    n = load().detexhipKernelName(fmt.texture_format)
+    return None if n is None else n.decode()
+
+
+def _stream_handle(stream):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def decompress_linear_device(fmt, blocks, width, height, out=None, pitch=None, pixel_format=None,
+                             status=None, stream=None, width_in_blocks=None, height_in_blocks=None):
+    """detexhipDecompressTextureLinearDevice on torch CUDA tensors (uint8).  Asynchronous on the
+    current (or given) torch stream.  Returns the output tensor (height, pitch) bytes."""
+    import torch
+    lib = load()
+    pf = F.native_pixel_format(fmt) if pixel_format is None else pixel_format
+    px = 1 + ((pf & 0xF00) >> 8)
+    wb = (width + 3) // 4 if width_in_blocks is None else width_in_blocks
+    hb = (height + 3) // 4 if height_in_blocks is None else height_in_blocks
+    pitch = width * px if pitch is None else pitch
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+    assert blocks.numel() >= wb * hb * fmt.block_bytes
+    if out is None:
+        out = torch.empty(height * pitch, dtype=torch.uint8, device=blocks.device)
+    assert out.is_cuda and out.numel() >= (height - 1) * pitch + width * px if height > 0 else True
+    _check(lib.detexhipDecompressTextureLinearDevice(
+        fmt.texture_format, blocks.data_ptr(), width, height, wb, hb, out.data_ptr(), pitch, pf,
+        _stream_handle(stream), None if status is None else status.data_ptr()),
+        "detexhipDecompressTextureLinearDevice")
+    return out
+
+
+def decompress_tiled_device(fmt, blocks, wb, hb, out=None, pixel_format=None, status=None, stream=None):
+    import torch
+    lib = load()
+    pf = F.native_pixel_format(fmt) if pixel_format is None else pixel_format
+    px = 1 + ((pf & 0xF00) >> 8)
+    if out is None:
+        out = torch.empty(wb * hb * 16 * px, dtype=torch.uint8, device=blocks.device)
+    _check(lib.detexhipDecompressTextureTiledDevice(
+        fmt.texture_format, blocks.data_ptr(), wb, hb, out.data_ptr(), pf, _stream_handle(stream),
+        None if status is None else status.data_ptr()), "detexhipDecompressTextureTiledDevice")
+    return out
+
+
+def decompress_blocks_device(fmt, blocks, n_blocks, mode_mask=F.MODE_MASK_ALL, flags=0, out=None, ok=None,
+                             stream=None):
+    """Batched per-block API: returns (pixels[n*16*px] uint8, ok[n] uint8)."""
+    import torch
+    lib = load()
+    if out is None:
+        out = torch.empty(n_blocks * 16 * fmt.pixel_bytes, dtype=torch.uint8, device=blocks.device)
+    if ok is None:
+        ok = torch.empty(max(n_blocks, 1), dtype=torch.uint8, device=blocks.device)
+    _check(lib.detexhipDecompressBlocksDevice(
+        fmt.texture_format, blocks.data_ptr(), n_blocks, mode_mask, flags, out.data_ptr(), ok.data_ptr(),
+        _stream_handle(stream)), "detexhipDecompressBlocksDevice")
+    return out, ok

@@ -1,0 +1,148 @@
+// decode_bptc.h -- BPTC (BC7), all eight modes, one lane per block, gfx950.
+//
+// The reference decodes with an 8-way mode switch, a bit-at-a-time 128-bit reader and per-texel
+// table lookups (decompress-bptc.c:354-512).  A wavefront of 64 independent blocks would execute
+// every taken mode path serially, so this decoder is a single DIVERGENCE-FREE data-driven path:
+// the per-mode layout (subsets, field widths, P-bit kind, index widths) is one packed descriptor
+// word fetched from __constant__ memory by the lane's mode, every field position is computed
+// arithmetically, fields are pulled out of the 128-bit block with funnel shifts, endpoints are
+// expanded to 8 bits with SWAR byte math and texels are blended two channels per multiply.
+// Partition / anchor tables are the bit-packed words of bptc_tables.inc in __constant__ memory.
+//
+// Reference quirk reproduced: in mode 6 the second P-bit (block bit 64) reads 0.
+#pragma once
+#include "dev_common.h"
+#include "decode_s3tc_rgtc.h"
+#include "bptc_tables.inc"
+
+namespace detexhip {
+
+// [0..63] two-subset partitions, [64..127] three-subset partitions; 2-bit subset field per texel
+__constant__ uint32_t kPartition2Bit[128] = { DETEXHIP_P2X_WORDS, DETEXHIP_P3_WORDS };
+// anchor2 | anchor3_second << 4 | anchor3_third << 8
+__constant__ uint16_t kAnchorWords[64] = { DETEXHIP_ANCHOR_WORDS };
+// one-bit-per-texel form of the two-subset partitions (BC6H)
+__constant__ uint16_t kPartition1Bit[64] = { DETEXHIP_P2_WORDS };
+
+// per-mode layout (decompress-bptc.c:24-43 comment table, :45-71, :134, :195-225, :265-267)
+constexpr uint32_t bc7_desc(uint32_t ns, uint32_t pb, uint32_t rb, uint32_t isb, uint32_t cb, uint32_t ab, uint32_t epb,
+		uint32_t spb, uint32_t ib, uint32_t ib2) {
+	return ns | (pb << 2) | (rb << 5) | (isb << 7) | (cb << 8) | (ab << 11) | (epb << 15) | (spb << 16) | (ib << 17) | (ib2 << 20);
+}
+__constant__ uint32_t kBc7ModeDesc[8] = {
+	//       subsets part rot isel colour alpha endpoint-P shared-P index index2
+	bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0),
+	bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0),
+	bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
+	bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0),
+	bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3),
+	bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
+	bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0),
+	bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0),
+};
+
+// weight(index) for a per-lane index width: (64*i + d/2) / d as multiply-shift (dev_common.h)
+struct WeightParams { uint32_t half, magic; };
+DH WeightParams weight_params(uint32_t bits) {
+	WeightParams w;
+	w.half = ((1u << bits) - 1u) >> 1;
+	w.magic = bits == 2 ? 21846u : (bits == 3 ? 9363u : 4370u);
+	return w;
+}
+DH uint32_t weight_of(uint32_t index, const WeightParams &w) { return (((index << 6) + w.half) * w.magic) >> 16; }
+
+struct DecBPTC {
+	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
+
+	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
+		const uint32_t low = blk.x & 0xFFu;
+		if (low == 0) return false;				// reserved (decompress-bptc.c:229-237, 361)
+		const uint32_t mode = (uint32_t)__builtin_ctz(low);
+		if (CHECKED) {						// :363-369
+			if (!(mode_mask & (1u << mode))) return false;
+			if (mode >= 4 && (flags & kFlagOpaqueOnly)) return false;
+			if (mode < 4 && (flags & kFlagNonOpaqueOnly)) return false;
+		}
+		const uint32_t desc = kBc7ModeDesc[mode];
+		const uint32_t ns = desc & 3u, pb = ubfe(desc, 2, 3), rb = ubfe(desc, 5, 2), isb = ubfe(desc, 7, 1);
+		const uint32_t cb = ubfe(desc, 8, 3), ab = ubfe(desc, 11, 4), epb = ubfe(desc, 15, 1), spb = ubfe(desc, 16, 1);
+		const uint32_t ib = ubfe(desc, 17, 3), ib2 = ubfe(desc, 20, 2);
+		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
+
+		// header fields all lie in the first 14 bits
+		uint32_t pos = mode + 1u;
+		const uint32_t part = ubfe(blk.x, pos, pb); pos += pb;
+		const uint32_t rot = ubfe(blk.x, pos, rb); pos += rb;
+		const uint32_t isel = ubfe(blk.x, pos, isb); pos += isb;
+
+		// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values) -- :74-132
+		const uint32_t chan = 2u * ns * cb;			// <= 30 bits per colour channel
+		const uint32_t wr = extract32(b, pos), wg = extract32(b, pos + chan), wb = extract32(b, pos + 2u * chan);
+		pos += 3u * chan;
+		const uint32_t wa = extract32(b, pos);
+		pos += 2u * ns * ab;
+		uint32_t pw = extract32(b, pos);			// P-bits: per endpoint, or per subset (mode 1)
+		pw = mode == 6u ? (pw & 1u) : pw;			// QUIRK A-2 (decompress-bptc.c:142-146)
+		pos += epb * 2u * ns + spb * ns;
+
+		// expand to 8 bits: append the P-bit, shift the MSB to bit 7, replicate the top bits (:136-180)
+		const uint32_t has_p = epb | spb;
+		const uint32_t cprec = cb + has_p, aprec = ab + epb;
+		const uint32_t c_up = 8u - cprec, c_down = (2u * cprec - 8u) & 31u;
+		const uint32_t a_up = (8u - aprec) & 31u, a_down = (2u * aprec - 8u) & 31u;
+		const uint32_t c_keep = 0x010101u * ((1u << c_up) - 1u);
+		uint32_t ep[6];
+#pragma unroll
+		for (int e = 0; e < 6; e++) {
+			const uint32_t off = (uint32_t)e * cb, offa = (uint32_t)e * ab;
+			uint32_t x = ubfe(wr, off, cb) | (ubfe(wg, off, cb) << 8) | (ubfe(wb, off, cb) << 16);
+			const uint32_t p = ubfe(pw, epb ? (uint32_t)e : (uint32_t)(e >> 1), 1) & has_p;
+			x = (x << has_p) | ((0u - p) & 0x010101u);
+			x = ((x << c_up) | ((x >> c_down) & c_keep)) & 0xFFFFFFu;
+			uint32_t a = ubfe(wa, offa, ab);
+			a = (a << epb) | (p & epb);
+			a = ((a << a_up) | (a >> a_down)) & 0xFFu;
+			a = mode < 4u ? 0xFFu : a;			// :176-179
+			ep[e] = x | (a << 24);
+		}
+
+		// partition + anchors (:391-400)
+		const uint32_t pword = ns == 1u ? 0u : kPartition2Bit[part + (ns == 3u ? 64u : 0u)];
+		const uint32_t an = kAnchorWords[part];
+		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
+		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
+
+		// index streams: primary (16*ib - ns bits), then secondary for modes 4/5 (16*ib2 - 1 bits) -- :401-480
+		const uint64_t prim = ((uint64_t)extract32(b, pos + 32u) << 32) | extract32(b, pos);
+		const uint32_t pos2 = pos + 16u * ib - ns;
+		const uint64_t sec = ((uint64_t)extract32(b, pos2 + 32u) << 32) | extract32(b, pos2);
+		const bool two = ib2 != 0u, swap = two && isel != 0u;
+		// colour uses the secondary indices when the index-selection bit is set (:374-375, 452-480)
+		const WeightParams wp_a = weight_params(ib), wp_b = weight_params(two ? ib2 : ib);
+		const uint32_t rotsel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u : (rot == 2u ? 0x01020300u : 0x02030100u));
+
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			const uint32_t is_anchor = (amask >> i) & 1u;
+			const uint32_t off = (uint32_t)i * ib - (uint32_t)__builtin_popcount(amask & ((1u << i) - 1u));
+			const uint32_t idx_a = ubfe((uint32_t)(prim >> off), 0, ib - is_anchor);
+			const uint32_t off2 = ((uint32_t)i * ib2 - (i > 0 ? 1u : 0u)) & 63u;	// unused (garbage) when ib2 == 0
+			const uint32_t idx_b2 = ubfe((uint32_t)(sec >> off2), 0, (ib2 - (i == 0 ? 1u : 0u)) & 31u);
+			const uint32_t w_a = weight_of(idx_a, wp_a);
+			const uint32_t w_b = two ? weight_of(idx_b2, wp_b) : w_a;
+			const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
+
+			const uint32_t m1 = bit_to_mask(pword, 2 * i), m2 = bit_to_mask(pword, 2 * i + 1);
+			const uint32_t e0 = bfi(m2, ep[4], bfi(m1, ep[2], ep[0])), e1 = bfi(m2, ep[5], bfi(m1, ep[3], ep[1]));
+			// ((64-w)*e0 + w*e1 + 32) >> 6, R and B together in 16-bit lanes (:182-193)
+			const uint32_t rb2 = ((e0 & 0x00FF00FFu) * (64u - wc) + (e1 & 0x00FF00FFu) * wc + 0x00200020u) >> 6;
+			const uint32_t g = (((e0 >> 8) & 0xFFu) * (64u - wc) + ((e1 >> 8) & 0xFFu) * wc + 32u) >> 6;
+			const uint32_t a = ((e0 >> 24) * (64u - wal) + (e1 >> 24) * wal + 32u) >> 6;
+			const uint32_t px = (rb2 & 0x00FF00FFu) | (g << 8) | (a << 24);
+			d[i] = perm(px, px, rotsel);			// rotation swaps A with R/G/B (:497-508)
+		}
+		return true;
+	}
+};
+
+}  // namespace detexhip

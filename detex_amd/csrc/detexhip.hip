@@ -1,0 +1,430 @@
+// detexhip.hip -- C-ABI boundary of libdetexhip (include/detex.h + include/detexhip.h).
+//
+// Host side of the drop-in: the reference's link-time C API for the block-decode path
+// (texture.c:55-145 drivers, the 19 leaf decoders of decompress-*.c, the misc.c:73-94 error
+// convention) re-implemented as a thin C++ shim over the HIP kernels of kernels.h.  There is
+// NO CPU decode in this library: every entry point, including the one-block leaf functions,
+// runs the gfx950 kernels; without a usable HIP device the calls fail with an error message.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define DETEXHIP_BUILDING_LIBRARY 1
+#include "../../include/detex.h"
+#include "../../include/detexhip.h"
+#include "decode_s3tc_rgtc.h"
+#include "decode_etc_eac.h"
+#include "decode_bptc.h"
+#include "decode_bptc_float.h"
+#include "kernels.h"
+#include "variant_tile4x4.h"
+
+using namespace detexhip;
+
+// ------------------------------------------------------------------------------------------------
+// error convention (misc.c:73-94): thread-local, malloc'ed, replaced on every error
+// ------------------------------------------------------------------------------------------------
+static thread_local char *t_error_message = nullptr;
+
+extern "C" void detexSetErrorMessage(const char *format, ...) {
+	va_list args;
+	va_start(args, format);
+	char *message = nullptr;
+	if (vasprintf(&message, format, args) < 0) message = strdup("detexSetErrorMessage: vasprintf returned error");
+	va_end(args);
+	free(t_error_message);
+	t_error_message = message;
+}
+
+extern "C" const char *detexGetErrorMessage(void) { return t_error_message; }
+
+#define HIP_TRY(expr, what)                                                                      \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) {                                                                  \
+			detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e_));     \
+			return false;                                                                        \
+		}                                                                                        \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------
+// format table: index = texture_format >> 24 (texture.c:27-48)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Geometry {
+	const void *blocks; void *pixels; uint32_t wb, hb, width, height; uint64_t pitch;
+	uint32_t *status; hipStream_t stream; int variant;
+};
+struct BatchArgs {
+	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
+	hipStream_t stream; bool checked;
+};
+
+template <class Dec> bool fast_geometry(const Geometry &g) {
+	return (g.width & 3u) == 0 && (g.height & 3u) == 0 && g.wb * 4u == g.width && g.hb * 4u == g.height &&
+		(reinterpret_cast<uintptr_t>(g.pixels) & 15u) == 0 && (g.pitch & 15u) == 0 &&
+		(Dec::kPixelBytes >= 4 || ((g.pitch % (4u * Dec::kPixelBytes)) == 0));
+}
+
+template <class Dec> hipError_t launch_linear(const Geometry &g) {
+	const uint32_t n = g.wb * g.hb;
+	if (n == 0) return hipSuccess;
+	const dim3 grid((n + 255u) / 256u), block(256);
+	uint8_t *px = static_cast<uint8_t *>(g.pixels);
+	if (fast_geometry<Dec>(g)) {
+		if (g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0)
+			return Tile4x4<Dec>::launch(g.blocks, px, g.wb, g.hb, g.pitch, g.status, g.stream);
+		if (g.variant == 2)
+			hipLaunchKernelGGL((decode_linear<Dec, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+		else
+			hipLaunchKernelGGL((decode_linear<Dec, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+	} else {
+		hipLaunchKernelGGL((decode_linear_clipped<Dec>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.width,
+			g.height, g.pitch, g.status);
+	}
+	return hipGetLastError();
+}
+
+template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
+	if (a.n == 0) return hipSuccess;
+	const dim3 grid((unsigned)((a.n + 255u) / 256u)), block(256);
+	uint8_t *px = static_cast<uint8_t *>(a.pixels);
+	if (a.checked)
+		hipLaunchKernelGGL((decode_blocks<Dec, true>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+			a.flags, a.ok, a.status);
+	else
+		hipLaunchKernelGGL((decode_blocks<Dec, false>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+			a.flags, a.ok, a.status);
+	return hipGetLastError();
+}
+
+struct FormatEntry {
+	const char *name;
+	uint32_t texture_format;
+	hipError_t (*linear)(const Geometry &);
+	hipError_t (*blocks)(const BatchArgs &);
+	const char *kernel_name;
+};
+
+#define FMT(NAME, DEC) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, "decode_linear<detexhip::" #DEC }
+
+const FormatEntry kFormats[20] = {
+	{ nullptr, 0, nullptr, nullptr, nullptr },
+	FMT(BC1, DecBC1), FMT(BC1A, DecBC1A), FMT(BC2, DecBC2), FMT(BC3, DecBC3),
+	FMT(RGTC1, DecRGTC1), FMT(SIGNED_RGTC1, DecSignedRGTC1), FMT(RGTC2, DecRGTC2), FMT(SIGNED_RGTC2, DecSignedRGTC2),
+	FMT(BPTC_FLOAT, DecBPTCFloat), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat), FMT(BPTC, DecBPTC),
+	FMT(ETC1, DecETC1), FMT(ETC2, DecETC2), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough), FMT(ETC2_EAC, DecETC2EAC),
+	FMT(EAC_R11, DecEACR11), FMT(EAC_SIGNED_R11, DecEACSignedR11), FMT(EAC_RG11, DecEACRG11),
+	FMT(EAC_SIGNED_RG11, DecEACSignedRG11),
+};
+
+const FormatEntry *lookup_format(uint32_t texture_format) {
+	const uint32_t idx = texture_format >> 24;
+	if (idx == 0 || idx >= 20) return nullptr;	// the reference indexes its table unchecked (SURVEY A-11)
+	return kFormats[idx].texture_format == texture_format ? &kFormats[idx] : nullptr;
+}
+
+// accepted targets: native, or the RGBX8 <-> RGBA8 no-op edge (convert.c:768-769, 1087-1092)
+bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) {
+	const uint32_t native = texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK;
+	if (pixel_format == native) return true;
+	const bool n8 = native == DETEX_PIXEL_FORMAT_RGBA8 || native == DETEX_PIXEL_FORMAT_RGBX8;
+	return n8 && (pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-thread device context: stream + grow-only staging buffers for the host-pointer tier
+// ------------------------------------------------------------------------------------------------
+struct ThreadContext {
+	bool ready = false;
+	int device = -1;
+	int variant = -1;
+	hipStream_t stream = nullptr;
+	void *d_in = nullptr, *d_out = nullptr;
+	size_t in_cap = 0, out_cap = 0;
+	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls
+	~ThreadContext() {
+		if (!ready) return;
+		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
+		(void)hipStreamDestroy(stream);
+	}
+};
+thread_local ThreadContext t_ctx;
+
+bool context_ready() {
+	ThreadContext &c = t_ctx;
+	if (c.ready) return true;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		detexSetErrorMessage("libdetexhip: no usable HIP device (%s); this library has no CPU decode path",
+			e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+		return false;
+	}
+	if (c.device < 0) {
+		const char *env = getenv("DETEXHIP_DEVICE");
+		c.device = env ? atoi(env) : 0;
+	}
+	HIP_TRY(hipSetDevice(c.device), "hipSetDevice");
+	HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
+	HIP_TRY(hipMalloc(&c.d_status, 64), "hipMalloc(status)");
+	c.ready = true;
+	return true;
+}
+
+int current_variant() {
+	ThreadContext &c = t_ctx;
+	if (c.variant < 0) {
+		const char *env = getenv("DETEXHIP_VARIANT");
+		c.variant = env ? atoi(env) : 0;
+		if (c.variant < 0 || c.variant > 2) c.variant = 0;
+	}
+	return c.variant;
+}
+
+bool reserve(void **buf, size_t *cap, size_t need) {
+	if (need <= *cap) return true;
+	if (*buf) HIP_TRY(hipFree(*buf), "hipFree");
+	*buf = nullptr; *cap = 0;
+	const size_t rounded = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+	HIP_TRY(hipMalloc(buf, rounded), "hipMalloc(staging)");
+	*cap = rounded;
+	return true;
+}
+
+// shared by the 19 leaf functions and detexDecompressBlock: one block through the GPU.
+// Returns 1 = decoded, 0 = the decoder returned false, -1 = HIP/runtime failure (message set).
+int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags,
+		uint8_t *pixel_buffer) {
+	if (!context_ready()) return -1;
+	ThreadContext &c = t_ctx;
+	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
+	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(f->texture_format);
+	if (!reserve(&c.d_in, &c.in_cap, 4096) || !reserve(&c.d_out, &c.out_cap, 4096)) return -1;
+	uint8_t *d_ok = reinterpret_cast<uint8_t *>(c.d_status + 1);
+	uint8_t host_out[DETEX_MAX_BLOCK_SIZE];
+	uint8_t ok = 0;
+	auto run = [&]() -> bool {
+		HIP_TRY(hipMemcpyAsync(c.d_in, bitstring, bs, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true };
+		HIP_TRY(f->blocks(a), "kernel launch");
+		HIP_TRY(hipMemcpyAsync(host_out, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+		HIP_TRY(hipMemcpyAsync(&ok, d_ok, 1, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		return true;
+	};
+	if (!run()) return -1;
+	if (!ok) return 0;
+	memcpy(pixel_buffer, host_out, out_bytes);
+	return 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// extension tier: device pointers (include/detexhip.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int detexhipGetDeviceCount(void) {
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+extern "C" int detexhipSetDevice(int device) {
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); return 1; }
+	if (t_ctx.ready && t_ctx.device != device) {
+		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d) after this thread already used device %d", device, t_ctx.device);
+		return 1;
+	}
+	t_ctx.device = device;
+	return 0;
+}
+
+extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
+
+extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 2) ? variant : 0; }
+extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
+
+extern "C" const char *detexhipKernelName(uint32_t texture_format) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) return nullptr;
+	if (current_variant() == 1 && (texture_format >> 24) == 1) return "decode_linear_tile4x4";
+	return f->kernel_name;
+}
+
+extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, const void *d_blocks, int width,
+		int height, int width_in_blocks, int height_in_blocks, void *d_pixels, size_t pitch_bytes,
+		uint32_t pixel_format, void *stream, uint32_t *d_status) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("detexhipDecompressTextureLinearDevice: 0x%08X is not a block-compressed format of this library", texture_format); return 1; }
+	if (!pixel_format_accepted(texture_format, pixel_format)) {
+		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: pixel format 0x%08X is outside the block-decode path for format 0x%08X", pixel_format, texture_format);
+		return 1;
+	}
+	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	if (width < 0 || height < 0 || width_in_blocks < 0 || height_in_blocks < 0 || pitch_bytes < (size_t)width * px ||
+			(pitch_bytes % px) != 0 || (reinterpret_cast<uintptr_t>(d_pixels) % px) != 0 ||
+			(uint64_t)width_in_blocks * (uint64_t)height_in_blocks > 0xFFFFFF00ull) {
+		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: bad geometry %dx%d (%dx%d blocks, pitch %zu)", width, height, width_in_blocks, height_in_blocks, pitch_bytes);
+		return 1;
+	}
+	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
+		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant() };
+	hipError_t e = f->linear(g);
+	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+	return 0;
+}
+
+static int blocks_device(const char *who, uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,
+		uint32_t flags, void *d_pixels, uint8_t *d_ok, uint32_t *d_status, void *stream, bool checked) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
+	if (n_blocks > 0xFFFFFF00ull) { detexSetErrorMessage("%s: too many blocks", who); return 1; }
+	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, flags, d_ok, d_status, static_cast<hipStream_t>(stream), checked };
+	hipError_t e = f->blocks(a);
+	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+	return 0;
+}
+
+extern "C" int detexhipDecompressTextureTiledDevice(uint32_t texture_format, const void *d_blocks, int width_in_blocks,
+		int height_in_blocks, void *d_pixels, uint32_t pixel_format, void *stream, uint32_t *d_status) {
+	if (lookup_format(texture_format) && !pixel_format_accepted(texture_format, pixel_format)) {
+		detexSetErrorMessage("detexhipDecompressTextureTiledDevice: pixel format 0x%08X is outside the block-decode path for format 0x%08X", pixel_format, texture_format);
+		return 1;
+	}
+	if (width_in_blocks < 0 || height_in_blocks < 0) { detexSetErrorMessage("detexhipDecompressTextureTiledDevice: bad geometry"); return 1; }
+	return blocks_device("detexhipDecompressTextureTiledDevice", texture_format, d_blocks,
+		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false);
+}
+
+extern "C" int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,
+		uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream) {
+	return blocks_device("detexhipDecompressBlocksDevice", texture_format, d_blocks, n_blocks, mode_mask, flags, d_pixels, d_ok,
+		nullptr, stream, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference tier: host pointers (include/detex.h)
+// ------------------------------------------------------------------------------------------------
+#define LEAF(NAME)                                                                                          \
+	extern "C" bool detexDecompressBlock##NAME(const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags, \
+			uint8_t *pixel_buffer) {                                                                         \
+		return decode_one_block(&kFormats[DETEX_TEXTURE_FORMAT_##NAME >> 24], bitstring, mode_mask, flags,  \
+			pixel_buffer) == 1;                                                                              \
+	}
+LEAF(BC1) LEAF(BC1A) LEAF(BC2) LEAF(BC3) LEAF(RGTC1) LEAF(SIGNED_RGTC1) LEAF(RGTC2) LEAF(SIGNED_RGTC2)
+LEAF(BPTC_FLOAT) LEAF(BPTC_SIGNED_FLOAT) LEAF(BPTC) LEAF(ETC1) LEAF(ETC2) LEAF(ETC2_PUNCHTHROUGH) LEAF(ETC2_EAC)
+LEAF(EAC_R11) LEAF(EAC_SIGNED_R11) LEAF(EAC_RG11) LEAF(EAC_SIGNED_RG11)
+#undef LEAF
+
+// texture.c:55-70
+extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_format, uint32_t mode_mask, uint32_t flags,
+		uint8_t *pixel_buffer, uint32_t pixel_format) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) {
+		detexSetErrorMessage("detexDecompressBlock: 0x%08X is not a block-compressed format of this library", texture_format);
+		return false;
+	}
+	if (!pixel_format_accepted(texture_format, pixel_format)) {
+		detexSetErrorMessage("detexDecompressBlock: conversion of format 0x%08X to pixel format 0x%08X is outside the "
+			"block-decode path of libdetexhip", texture_format, pixel_format);
+		return false;
+	}
+	const int r = decode_one_block(f, bitstring, mode_mask, flags, pixel_buffer);
+	if (r == 0)	// same text as the reference (texture.c:63-64); HIP failures have set their own message
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture_format);
+	return r == 1;
+}
+
+// shared body of the two texture drivers (texture.c:77-98, 105-145)
+static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format, bool tiled) {
+	const char *who = tiled ? "detexDecompressTextureTiled" : "detexDecompressTextureLinear";
+	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	const size_t wb = (size_t)texture->width_in_blocks, hb = (size_t)texture->height_in_blocks;
+	const size_t out_bytes = tiled ? wb * hb * 16u * px : (size_t)texture->width * (size_t)texture->height * px;
+	if (!detexFormatIsCompressed(texture->format)) {
+		if (tiled) { detexSetErrorMessage("detexDecompressTextureTiled: Cannot handle uncompressed texture format"); return false; }
+		// texture.c:108-111 hands uncompressed textures to detexConvertPixels; only its identity
+		// edge (convert.c:1087-1092) belongs to this path.
+		const uint32_t src = detexGetPixelFormat(texture->format);
+		const bool same8 = (src == DETEX_PIXEL_FORMAT_RGBA8 || src == DETEX_PIXEL_FORMAT_RGBX8) &&
+			(pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8);
+		if (src == pixel_format || same8) { memcpy(pixel_buffer, texture->data, out_bytes); return true; }
+		detexSetErrorMessage("%s: pixel conversion 0x%08X -> 0x%08X is outside the block-decode path of libdetexhip", who, src, pixel_format);
+		return false;
+	}
+	const FormatEntry *f = lookup_format(texture->format);
+	if (!f || !pixel_format_accepted(texture->format, pixel_format)) {
+		// the reference fails every block here: all-zero image and false
+		memset(pixel_buffer, 0, out_bytes);
+		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who,
+			texture->format, pixel_format);
+		return false;
+	}
+	if (out_bytes == 0 || wb * hb == 0) return true;
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	const size_t in_bytes = wb * hb * detexGetCompressedBlockSize(texture->format);
+	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, out_bytes)) return false;
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	HIP_TRY(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	int rc;
+	if (tiled)
+		rc = detexhipDecompressTextureTiledDevice(texture->format, c.d_in, texture->width_in_blocks, texture->height_in_blocks,
+			c.d_out, pixel_format, c.stream, c.d_status);
+	else
+		rc = detexhipDecompressTextureLinearDevice(texture->format, c.d_in, texture->width, texture->height,
+			texture->width_in_blocks, texture->height_in_blocks, c.d_out, (size_t)texture->width * px, pixel_format, c.stream,
+			c.d_status);
+	if (rc != 0) return false;
+	uint32_t status = 0;
+	HIP_TRY(hipMemcpyAsync(pixel_buffer, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	if (status != 0) {
+		// same text the reference leaves behind after a failed block (texture.c:63-64)
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+		return false;
+	}
+	return true;
+}
+
+extern "C" bool detexDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, true);
+}
+
+extern "C" bool detexDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// data symbols inlined helpers of the reference's detex.h refer to (detex.h:933,954,960,974):
+// generated at compile time, value = clamp / truncating division (never used by this library)
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int N> struct ByteTable { uint8_t v[N]; };
+template <int N, int D> constexpr ByteTable<N> make_division_table() {
+	ByteTable<N> t{};
+	for (int i = 0; i < N; i++) t.v[i] = (uint8_t)(i / D);
+	return t;
+}
+constexpr ByteTable<767> make_clamp_table() {
+	ByteTable<767> t{};
+	for (int i = 0; i < 767; i++) t.v[i] = (uint8_t)(i < 255 ? 0 : (i > 510 ? 255 : i - 255));
+	return t;
+}
+}  // namespace
+extern "C" {
+__attribute__((visibility("default"))) extern const ByteTable<767> detex_clamp0to255_table_storage __asm__("detex_clamp0to255_table");
+__attribute__((visibility("default"))) extern const ByteTable<768> detex_division_by_3_table_storage __asm__("detex_division_by_3_table");
+__attribute__((visibility("default"))) extern const ByteTable<1792> detex_division_by_7_table_storage __asm__("detex_division_by_7_table");
+__attribute__((visibility("default"))) extern const ByteTable<1280> detex_division_by_5_table_storage __asm__("detex_division_by_5_table");
+const ByteTable<767> detex_clamp0to255_table_storage = make_clamp_table();
+const ByteTable<768> detex_division_by_3_table_storage = make_division_table<768, 3>();
+const ByteTable<1792> detex_division_by_7_table_storage = make_division_table<1792, 7>();
+const ByteTable<1280> detex_division_by_5_table_storage = make_division_table<1280, 5>();
+}

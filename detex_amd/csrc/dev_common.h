@@ -1,0 +1,84 @@
+// dev_common.h -- device-side helpers shared by the gfx950 block decoders.
+//
+// Everything here is integer bit manipulation mapped 1:1 onto CDNA4 VALU ops
+// (v_bfe_u32/i32, v_bfi_b32, v_perm_b32, v_med3_i32, v_mul_u32_u24): the decode path has no
+// floating point and no MFMA work.  The exact-division helpers are
+// DETEX_HD so that tests/test_intmath.py can compile them for the host and prove them
+// exhaustively equal to C integer division on the domains the reference's LUTs cover
+// (division-tables.c: 0..767 /3, 0..1279 /5, 0..1791 /7).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DETEX_HD __host__ __device__ __forceinline__
+#define DH __device__ __forceinline__
+#define DETEXHIP_DEVICE_CODE 1
+#elif defined(DETEXHIP_HOST_EMULATION)
+// test-only: tests/host_emul/hip_host_shim.h emulates the gfx950 builtins so the decoders below
+// can be exercised by g++ in containers without a GPU (never part of libdetexhip.so)
+#include "hip_host_shim.h"
+#define DETEX_HD static inline
+#define DETEXHIP_DEVICE_CODE 1
+#else
+#define DETEX_HD static inline
+#endif
+
+namespace detexhip {
+
+// ---- exact small-domain unsigned division by multiply-shift (products < 2^24 * 2^16) -----
+DETEX_HD uint32_t div3_u(uint32_t x) { return (x * 43691u) >> 17; }  // exact for x < 98304
+DETEX_HD uint32_t div5_u(uint32_t x) { return (x * 52429u) >> 18; }  // exact for x < 81920
+DETEX_HD uint32_t div7_u(uint32_t x) { return (x * 9363u) >> 16; }   // exact for x < 2048*... (tested to 4095)
+// truncating signed division (detex.h:966-982 semantics: sign(v) * (|v| / d))
+DETEX_HD int32_t div7_s(int32_t v) { int32_t q = (int32_t)div7_u((uint32_t)(v < 0 ? -v : v)); return v < 0 ? -q : q; }
+DETEX_HD int32_t div5_s(int32_t v) { int32_t q = (int32_t)div5_u((uint32_t)(v < 0 ? -v : v)); return v < 0 ? -q : q; }
+// BPTC interpolation weight of an n-bit index: (64*i + (2^n-1)/2) / (2^n-1), n in {2,3,4}
+// (bptc-tables.c aWeight2/3/4 in closed form; magic = ceil(65536/d))
+DETEX_HD uint32_t bptc_weight(uint32_t index, uint32_t bits) {
+	const uint32_t d = (1u << bits) - 1u;
+	const uint32_t magic = bits == 2 ? 21846u : (bits == 3 ? 9363u : 4370u);
+	return (((index << 6) + (d >> 1)) * magic) >> 16;
+}
+// signed-RGTC value map [-127,127] -> int16 (decompress-rgtc.c:125-126): (v+127)*65535/254 - 32768
+DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) { return (((uint32_t)(v + 127) * 65535u) / 254u - 32768u) & 0xFFFFu; }
+
+#if defined(DETEXHIP_DEVICE_CODE)
+// ---- single-instruction bit-field idioms ---------------------------------------------------
+DH uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+DH int32_t sbfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_sbfe((int32_t)v, off, width); }
+// all-ones if bit `bit` of v is set, else 0 (v_bfe_i32 of a 1-bit field)
+DH uint32_t bit_to_mask(uint32_t v, uint32_t bit) { return (uint32_t)__builtin_amdgcn_sbfe((int32_t)v, bit, 1u); }
+// (a & m) | (b & ~m)  -> v_bfi_b32
+DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+// byte permute: result byte i = byte sel[i] of the 8-byte pool {s0 (4..7), s1 (0..3)}; 0x0C -> 0x00
+DH uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+DH int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
+DH uint32_t clamp255(int32_t v) { return (uint32_t)clampi(v, 0, 255); }
+DH uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
+DH uint32_t bswap32(uint32_t v) { return perm(0u, v, 0x00010203u); }
+
+// 4-way select of packed values by a 2-bit selector held as two lane masks
+DH uint32_t select4(uint32_t m_lo, uint32_t m_hi, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+	return bfi(m_hi, bfi(m_lo, p3, p2), bfi(m_lo, p1, p0));
+}
+
+// spread four 3-bit codes (bits 0..11 of c) into the four bytes of a v_perm selector
+DH uint32_t spread3to8(uint32_t c) {
+	return (c & 0x7u) | ((c << 5) & 0x700u) | ((c << 10) & 0x70000u) | ((c << 15) & 0x7000000u);
+}
+
+// ---- 128-bit little-endian block viewed as four dwords -------------------------------------
+struct Bits128 { uint32_t w[4]; };
+// bits [pos, pos+32) of the block, pos in 0..127 per lane (bits beyond 127 read as 0).
+// Two funnel shifts over a dword pair selected by pos>>5: no dynamic register indexing.
+DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
+	const uint32_t k = pos >> 5, s = pos & 31u;
+	const uint32_t lo = k == 0 ? b.w[0] : (k == 1 ? b.w[1] : (k == 2 ? b.w[2] : (k == 3 ? b.w[3] : 0u)));
+	const uint32_t hi = k == 0 ? b.w[1] : (k == 1 ? b.w[2] : (k == 2 ? b.w[3] : 0u));
+	return __builtin_amdgcn_alignbit(hi, lo, s);	// ({hi,lo} >> s)[31:0]
+}
+DH uint32_t extract_bits(const Bits128 &b, uint32_t pos, uint32_t n) { return ubfe(extract32(b, pos), 0, n); }
+#endif  // DETEXHIP_DEVICE_CODE
+
+}  // namespace detexhip

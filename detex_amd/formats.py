@@ -66,6 +66,15 @@ def native_pixel_format(fmt):
     return fmt.texture_format & 0xFFFF
 
 
+_PIXEL_NAMES = {0x334: "RGBA8", 0x320: "RGBA8", 0x000: "R8", 0x110: "RG8", 0x101: "R16", 0x1101: "SIGNED_R16",
+                0x311: "RG16", 0x1311: "SIGNED_RG16", 0x2721: "FLOAT_RGBX16", 0x3721: "SIGNED_FLOAT_RGBX16"}
+
+
+def target_name(fmt):
+    """display name of the decode target (RGBX8 natives are byte-identical to RGBA8, alpha = 0xFF)"""
+    return _PIXEL_NAMES[native_pixel_format(fmt)]
+
+
 def accepted_pixel_formats(fmt):
     """Target pixel formats the block-decode path supports for ``fmt``: the native one, plus
     the RGBX8<->RGBA8 no-op edge of the reference's conversion table (convert.c:768-769)."""

@@ -1,0 +1,83 @@
+/*
+ * include/detexhip.h -- device-pointer extension API of libdetexhip.
+ *
+ * The reference has no device boundary: every caller of its hot path
+ * (detexDecompressTextureLinear, texture.c:105; callers validate.c:208, detex-view.c:182,
+ * detex-convert.c:310) hands over HOST pointers.  libdetexhip keeps those entry points
+ * (include/detex.h) and adds this second tier for callers whose blocks and pixels already
+ * live in GPU memory -- the tier the roofline numbers are measured on.
+ *
+ * Plain C ABI: pointers, sizes, an opaque stream handle (a hipStream_t passed as void *;
+ * NULL = the null stream).  No torch / C++ types cross this boundary.  All launches are
+ * asynchronous on the given stream; nothing here synchronises.
+ *
+ * Return value: 0 on success (work enqueued), non-zero on a usage / HIP error, in which case
+ * detexGetErrorMessage() (detex.h:806 convention, thread-local) describes it.
+ */
+#ifndef DETEXHIP_H
+#define DETEXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DETEXHIP_API __attribute__((visibility("default")))
+
+/* Library / device management.  The device is per calling thread, like hipSetDevice. */
+DETEXHIP_API int detexhipGetDeviceCount(void);
+DETEXHIP_API int detexhipSetDevice(int device);
+DETEXHIP_API const char *detexhipVersion(void);
+
+/*
+ * Device-resident counterpart of detexDecompressTextureLinear (texture.c:105-145).
+ *   texture_format   DETEX_TEXTURE_FORMAT_* (detex.h:613-727)
+ *   d_blocks         width_in_blocks*height_in_blocks blocks of 8/16 bytes, row-major
+ *                    (texture.c:141), 8/16-byte aligned
+ *   width,height     image size in pixels; blocks are clipped to it (texture.c:116-136)
+ *   d_pixels         row-major image, row r at d_pixels + r*pitch_bytes
+ *   pitch_bytes      >= width*pixel_size; the reference's layout is exactly width*pixel_size.
+ *                    Rows are written with 16-byte vector stores when width%4 == 0, d_pixels
+ *                    and pitch_bytes are 16-byte aligned; any other geometry takes the clipped
+ *                    per-pixel path (d_pixels, pitch_bytes aligned to the pixel size).
+ *   pixel_format     native pixel format of texture_format, or RGBA8/RGBX8 for either
+ *   d_status         optional device uint32_t: set to 1 by the kernel if any block was invalid
+ *                    (those blocks are zero-filled, decoding continues: texture.c:125-128).
+ *                    The caller zeroes it beforehand and reads it after synchronising;
+ *                    result == (status == 0) is the reference's bool return value.
+ */
+DETEXHIP_API int detexhipDecompressTextureLinearDevice(uint32_t texture_format, const void *d_blocks,
+	int width, int height, int width_in_blocks, int height_in_blocks,
+	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status);
+
+/* Device-resident counterpart of detexDecompressTextureTiled (texture.c:77-98): block i
+ * occupies 16*pixel_size contiguous bytes of d_pixels; no clipping. */
+DETEXHIP_API int detexhipDecompressTextureTiledDevice(uint32_t texture_format, const void *d_blocks,
+	int width_in_blocks, int height_in_blocks, void *d_pixels, uint32_t pixel_format,
+	void *stream, uint32_t *d_status);
+
+/* Batched counterpart of the per-block functions detexDecompressBlock<FMT>
+ * (detex.h:435-531): n_blocks independent blocks, honouring mode_mask and flags exactly as
+ * the reference's leaf functions do.  Output is block-major, native pixel format; d_ok[i]
+ * (uint8_t, optional) receives the leaf function's bool; failed blocks are zero-filled. */
+DETEXHIP_API int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
+	uint32_t mode_mask, uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream);
+
+/* Kernel-variant selection for A/B measurements (bench.py --variant):
+ *   0  lane-per-block, 64x1-block wave tiles (default)
+ *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 family only]
+ *   2  as 0 with non-temporal row stores
+ * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
+DETEXHIP_API void detexhipSetKernelVariant(int variant);
+DETEXHIP_API int detexhipGetKernelVariant(void);
+
+/* Name of the HIP kernel the linear-device entry would launch for this format with the
+ * current variant (for matching rocprofv3 kernel-trace rows); NULL if unsupported. */
+DETEXHIP_API const char *detexhipKernelName(uint32_t texture_format);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

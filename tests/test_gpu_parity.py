@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI of libdetexhip.so, against
+(1) the committed goldens produced by the compiled reference and (2) the CPU oracle on the same
+seeded inputs.  Bit-exact everywhere: the whole path is integer / byte work.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+Nothing here reads /root/reference.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import streams
+from detex_amd import formats as F
+
+pytestmark = pytest.mark.gpu
+
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+FMT_IDS = [f.name for f in F.FORMATS]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda()
+
+
+def _first_diff(a, b, per):
+    a = np.asarray(a).reshape(-1, per); b = np.asarray(b).reshape(-1, per)
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    return "first differing unit %d of %d differing: got %s want %s" % (bad[0], len(bad), a[bad[0]][:16], b[bad[0]][:16])
+
+
+# ---- (i) the reference's bundled fixtures, end to end through the reference's own entry point ----
+@pytest.mark.parametrize("fmt", [f for f in F.FORMATS if f.fixture], ids=lambda f: f.name)
+def test_fixture_host_api(fmt, hiplib, golden_json, oracle):
+    from detex_amd.ktx import read_ktx
+    k = read_ktx(os.path.join(os.path.dirname(__file__), "golden", fmt.fixture))
+    want = golden_json("fixtures.json")[fmt.name]
+    for pf in F.accepted_pixel_formats(fmt):
+        ok, out = hiplib.linear(fmt, k["data"], k["width"], k["height"], pixel_format=pf)
+        g = want["0x%04X" % pf]
+        assert ok == g["ok"]
+        assert out.size == g["bytes"]
+        assert sha(out) == g["sha256"], fmt.name
+    ok_o, out_o = oracle.linear(fmt, k["data"], 64, 64)
+    assert np.array_equal(out, out_o)
+    ok_t, out_t = hiplib.tiled(fmt, k["data"], 16, 16)
+    ok_ot, out_ot = oracle.tiled(fmt, k["data"], 16, 16)
+    assert ok_t == ok_ot and np.array_equal(out_t, out_ot)
+
+
+# ---- (ii) mode-forced vectors: every mode / invalid class, per-block results + ok flags ----------
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_forced_vectors_device(fmt, torch_cuda, forced_vectors):
+    from detex_amd import binding
+    torch = torch_cuda
+    blocks = forced_vectors[fmt.name + "/in"]; want = forced_vectors[fmt.name + "/out"]; want_ok = forced_vectors[fmt.name + "/ok"]
+    n = len(blocks)
+    out, ok = binding.decompress_blocks_device(fmt, _dev(torch, blocks), n)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy().reshape(n, -1); ok = ok.cpu().numpy()[:n]
+    assert np.array_equal(ok, want_ok), "ok flags differ at %s" % np.nonzero(ok != want_ok)[0][:8]
+    assert np.array_equal(out, want), _first_diff(out, want, want.shape[1])
+
+
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_mask_flag_matrix_device(fmt, torch_cuda, forced_vectors, golden_json, oracle):
+    from detex_amd import binding
+    torch = torch_cuda
+    blocks = forced_vectors[fmt.name + "/in"]
+    n = len(blocks)
+    d_blocks = _dev(torch, blocks)
+    golden = golden_json("maskflags.json")[fmt.name]
+    for mask, flags in streams.MASK_FLAG_MATRIX:
+        out, ok = binding.decompress_blocks_device(fmt, d_blocks, n, mode_mask=mask, flags=flags)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy().reshape(n, -1); ok = ok.cpu().numpy()[:n]
+        g = golden["%08X/%X" % (mask, flags)]
+        want_ok = np.unpackbits(np.frombuffer(bytes.fromhex(g["ok_bits"]), np.uint8))[:n]
+        assert np.array_equal(ok, want_ok), (fmt.name, hex(mask), flags)
+        if sha(out) != g["sha256"]:
+            ok_o, out_o = oracle.blocks(fmt, blocks, mask, flags)
+            raise AssertionError("%s mask %08X flags %X: %s" % (fmt.name, mask, flags, _first_diff(out, out_o, out.shape[1])))
+
+
+# ---- per-block host API (the 19 leaf functions + detexDecompressBlock) on the GPU ----------------
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_leaf_functions_host_api(fmt, hiplib, forced_vectors):
+    blocks = forced_vectors[fmt.name + "/in"]; want = forced_vectors[fmt.name + "/out"]; want_ok = forced_vectors[fmt.name + "/ok"]
+    step = max(1, len(blocks) // 48)
+    for i in list(range(0, len(blocks), step)) + [len(blocks) - 1]:
+        ok, out = hiplib.block(fmt, blocks[i])
+        assert ok == bool(want_ok[i]), (fmt.name, i)
+        if ok:
+            assert np.array_equal(out, want[i]), (fmt.name, i)
+    # generic entry: error text of the reference on a failing block (texture.c:63-64)
+    bad = np.nonzero(want_ok == 0)[0]
+    import ctypes
+    out = np.zeros(16 * fmt.pixel_bytes, np.uint8)
+    if len(bad):
+        r = hiplib.lib.detexDecompressBlock(ol._ptr(blocks[bad[0]]), fmt.texture_format, 0xFFFFFFFF, 0, ol._ptr(out), F.native_pixel_format(fmt))
+        assert not r
+        assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+    good = np.nonzero(want_ok == 1)[0][0]
+    r = hiplib.lib.detexDecompressBlock(ol._ptr(blocks[good]), fmt.texture_format, 0xFFFFFFFF, 0, ol._ptr(out), F.native_pixel_format(fmt))
+    assert r and np.array_equal(out, want[good])
+
+
+# ---- (iii) clipped sizes through the host API and the device API with a padded pitch -------------
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_clipped_sizes(fmt, hiplib, torch_cuda, forced_vectors, clip_vectors):
+    from detex_amd import binding
+    torch = torch_cuda
+    flat = forced_vectors[fmt.name + "/in"].reshape(-1)
+    px = fmt.pixel_bytes
+    for (w, h) in streams.CLIP_SIZES:
+        wb, hb = (w + 3) // 4, (h + 3) // 4
+        data = np.resize(flat, wb * hb * fmt.block_bytes)
+        want = clip_vectors["%s/%dx%d" % (fmt.name, w, h)]
+        want_ok = bool(clip_vectors["%s/%dx%d/ok" % (fmt.name, w, h)][0])
+        ok, out = hiplib.linear(fmt, data, w, h)
+        assert ok == want_ok, (fmt.name, w, h)
+        assert np.array_equal(out, want), (fmt.name, w, h, _first_diff(out, want, px))
+        # device tier: pitch padded to 64 bytes, canary bytes beyond each row must survive
+        pitch = ((w * px + 63) // 64) * 64 + 64
+        canvas = torch.full((h * pitch,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        binding.decompress_linear_device(fmt, _dev(torch, data), w, h, out=canvas, pitch=pitch, status=status)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy().reshape(h, pitch)
+        assert np.array_equal(got[:, :w * px].reshape(-1), want), (fmt.name, w, h, "device pitch")
+        assert (got[:, w * px:] == 0xA5).all(), (fmt.name, w, h, "wrote outside the image")
+        assert bool(status.item() == 0) == want_ok
+
+
+# ---- random streams vs the oracle at a size the oracle finishes in well under a second ----------
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+@pytest.mark.parametrize("variant", [0, 2])
+def test_random_stream_vs_oracle(fmt, variant, torch_cuda, oracle):
+    from detex_amd import binding
+    torch = torch_cuda
+    W, H = 1024, 512
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0xC0FFEE + fmt.index)
+    ok_o, want = oracle.linear(fmt, data, W, H)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    binding.set_kernel_variant(variant)
+    try:
+        out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+        torch.cuda.synchronize()
+    finally:
+        binding.set_kernel_variant(0)
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want), _first_diff(got, want, 16 * fmt.pixel_bytes)
+    assert bool(status.item() == 0) == ok_o
+    # tiled layout of the same stream
+    ok_t, want_t = oracle.tiled(fmt, data, W // 4, H // 4)
+    got_t = binding.decompress_tiled_device(fmt, _dev(torch, data), W // 4, H // 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_t.cpu().numpy(), want_t)
+
+
+def test_bc1_tile4x4_variant_matches(torch_cuda, oracle):
+    """the north_star tile-shape variant (A/B only) decodes identically"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME["BC1"]
+    W, H = 2048, 256
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=77)
+    _, want = oracle.linear(fmt, data, W, H)
+    binding.set_kernel_variant(1)
+    try:
+        out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H)
+        torch.cuda.synchronize()
+    finally:
+        binding.set_kernel_variant(0)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+# ---- (iv) BASELINE.json's full size: 8192x8192 streams against the reference's digests ----------
+HEADLINE = ["BC1", "BC3", "BPTC", "ETC2", "ETC2_EAC", "BPTC_FLOAT"]
+
+
+@pytest.mark.parametrize("name", [f.name for f in F.FORMATS])
+def test_full_size_digest(name, torch_cuda, golden_json):
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    dg = golden_json("digests_8192.json")
+    W, H = dg["width"], dg["height"]
+    kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT") else [])
+    for kind in kinds:
+        g = dg["streams"]["%s/%s" % (name, kind)]
+        data = ol.stream_u(fmt, (W // 4) * (H // 4))
+        if kind == "M":
+            data = streams.stream_m(fmt, data)
+        assert sha(data) == g["in_sha256"], "stream generator drifted"
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+        torch.cuda.synchronize()
+        assert bool(status.item() == 0) == g["ok"], (name, kind)
+        assert sha(out.cpu().numpy()) == g["sha256"], (name, kind)
+        del out
+        torch.cuda.empty_cache()
+
+
+# ---- size-independent properties at full size -----------------------------------------------------
+def test_properties_full_size(torch_cuda):
+    """(a) row-band sharding: decoding block-row bands separately into the same image is
+    identical to one whole-image decode (the multi-GPU decomposition of SURVEY 8e);
+    (b) linear and tiled layouts hold the same texels; (c) decode is idempotent."""
+    from detex_amd import binding
+    torch = torch_cuda
+    for name in ("BC1", "BPTC"):
+        fmt = F.BY_NAME[name]
+        W = H = 4096
+        wb, hb = W // 4, H // 4
+        d_blocks = _dev(torch, ol.stream_u(fmt, wb * hb, seed=99))
+        whole = binding.decompress_linear_device(fmt, d_blocks, W, H)
+        again = binding.decompress_linear_device(fmt, d_blocks, W, H)
+        banded = torch.zeros_like(whole)
+        px = fmt.pixel_bytes
+        for g in range(8):
+            r0, r1 = g * hb // 8, (g + 1) * hb // 8
+            binding.decompress_linear_device(fmt, d_blocks[r0 * wb * fmt.block_bytes:], W, (r1 - r0) * 4,
+                                             out=banded[r0 * 4 * W * px:])
+        tiled = binding.decompress_tiled_device(fmt, d_blocks, wb, hb)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, again)
+        assert torch.equal(whole, banded)
+        t = tiled.view(hb, wb, 4, 4 * px).permute(0, 2, 1, 3).reshape(-1)
+        assert torch.equal(t, whole)
+
+
+def test_unsupported_targets_fail_loudly(hiplib):
+    fmt = F.BY_NAME["BC1"]
+    data = np.zeros(16 * 16 * 8, np.uint8)
+    out = np.full(64 * 64 * 8, 0x5A, np.uint8)
+    ok, out = hiplib.linear(fmt, data, 64, 64, pixel_format=0x6735, out=out)    # FLOAT_RGBA16: unreachable in the reference too
+    assert not ok and not out.any()
+    assert "outside the block-decode path" in hiplib.error()
