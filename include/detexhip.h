@@ -66,9 +66,9 @@ DETEXHIP_API int detexhipDecompressBlocksDevice(uint32_t texture_format, const v
 	uint32_t mode_mask, uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream);
 
 /* Kernel-variant selection for A/B measurements (bench.py --variant):
- *   0  lane-per-block, 64x1-block wave tiles (default)
- *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 family only]
- *   2  as 0 with non-temporal row stores
+ *   0  lane-per-block, 64x1-block wave tiles, non-temporal row stores (default)
+ *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 only]
+ *   2  as 0 with ordinary (cached) row stores
  * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);
