@@ -49,21 +49,51 @@ DH WeightParams weight_params(uint32_t bits) {
 	w.magic = bits == 2 ? 21846u : (bits == 3 ? 9363u : 4370u);
 	return w;
 }
-DH uint32_t weight_of(uint32_t index, const WeightParams &w) { return (((index << 6) + w.half) * w.magic) >> 16; }
+DH uint32_t weight_of(uint32_t index, const WeightParams &w) { return DETEX_UMUL24((index << 6) + w.half, w.magic) >> 16; }
 
-struct DecBPTC {
+// packed 2 x u16 arithmetic in one VGPR (v_pk_mad_u16 / v_pk_sub_u16): lanes wrap mod 2^16
+typedef uint16_t pk16 __attribute__((vector_size(4)));
+DH pk16 as_pk16(uint32_t v) { pk16 r; __builtin_memcpy(&r, &v, 4); return r; }
+DH uint32_t from_pk16(pk16 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+DH uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return from_pk16(as_pk16(a) * as_pk16(b) + as_pk16(c)); }
+DH uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return from_pk16(as_pk16(a) - as_pk16(b)); }
+
+// One subset's endpoint pair prepared for blending.  With e0, e1 in 0..255 and w in 0..64 the
+// reference's ((64-w)*e0 + w*e1 + 32) >> 6 (decompress-bptc.c:182-193) equals the high byte of
+//     256*e0 + 128 + 4*w*(e1 - e0)          (range 128 .. 65408: fits a 16-bit lane, exact mod 2^16)
+// so a texel is two v_pk_mad_u16 (R,G and B,A lanes) and one v_perm_b32 that gathers the four
+// high bytes (and applies the mode 4/5 channel rotation for free).
+struct BlendPair { uint32_t base_rg, base_ba, diff_rg, diff_ba; };
+DH BlendPair blend_pair(uint32_t e0, uint32_t e1) {
+	const uint32_t rg0 = perm(0u, e0, 0x0C010C00u), ba0 = perm(0u, e0, 0x0C030C02u);	// zero-extended channel pairs
+	const uint32_t rg1 = perm(0u, e1, 0x0C010C00u), ba1 = perm(0u, e1, 0x0C030C02u);
+	BlendPair p;
+	p.base_rg = (rg0 << 8) | 0x00800080u;
+	p.base_ba = (ba0 << 8) | 0x00800080u;
+	p.diff_rg = pk_sub_u16(rg1, rg0);
+	p.diff_ba = pk_sub_u16(ba1, ba0);
+	return p;
+}
+
+// FIXED_MODE >= 0 instantiates the decoder for one mode with every layout parameter a compile-time
+// constant (used by wave-uniform fast paths); FIXED_MODE = -1 is the per-lane data-driven form.
+template <int FIXED_MODE> struct DecBPTCMode {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
 
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		const uint32_t low = blk.x & 0xFFu;
 		if (low == 0) return false;				// reserved (decompress-bptc.c:229-237, 361)
-		const uint32_t mode = (uint32_t)__builtin_ctz(low);
+		const uint32_t mode = FIXED_MODE >= 0 ? (uint32_t)FIXED_MODE : (uint32_t)__builtin_ctz(low);
 		if (CHECKED) {						// :363-369
 			if (!(mode_mask & (1u << mode))) return false;
 			if (mode >= 4 && (flags & kFlagOpaqueOnly)) return false;
 			if (mode < 4 && (flags & kFlagNonOpaqueOnly)) return false;
 		}
-		const uint32_t desc = kBc7ModeDesc[mode];
+		constexpr uint32_t kDesc[8] = {
+			bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0), bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0), bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
+			bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0), bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3), bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
+			bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0), bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0) };
+		const uint32_t desc = FIXED_MODE >= 0 ? kDesc[FIXED_MODE >= 0 ? FIXED_MODE : 0] : kBc7ModeDesc[mode];
 		const uint32_t ns = desc & 3u, pb = ubfe(desc, 2, 3), rb = ubfe(desc, 5, 2), isb = ubfe(desc, 7, 1);
 		const uint32_t cb = ubfe(desc, 8, 3), ab = ubfe(desc, 11, 4), epb = ubfe(desc, 15, 1), spb = ubfe(desc, 16, 1);
 		const uint32_t ib = ubfe(desc, 17, 3), ib2 = ubfe(desc, 20, 2);
@@ -105,6 +135,7 @@ struct DecBPTC {
 			a = mode < 4u ? 0xFFu : a;			// :176-179
 			ep[e] = x | (a << 24);
 		}
+		const BlendPair s0 = blend_pair(ep[0], ep[1]), s1 = blend_pair(ep[2], ep[3]), s2 = blend_pair(ep[4], ep[5]);
 
 		// partition + anchors (:391-400)
 		const uint32_t pword = ns == 1u ? 0u : kPartition2Bit[part + (ns == 3u ? 64u : 0u)];
@@ -112,37 +143,45 @@ struct DecBPTC {
 		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
 		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
 
-		// index streams: primary (16*ib - ns bits), then secondary for modes 4/5 (16*ib2 - 1 bits) -- :401-480
-		const uint64_t prim = ((uint64_t)extract32(b, pos + 32u) << 32) | extract32(b, pos);
+		// index streams, consumed LSB-first: primary (16*ib - ns bits), then, for modes 4/5, the
+		// secondary one (16*ib2 - 1 bits) -- :401-480.  Each is a {hi,lo} pair advanced by funnel shifts.
+		uint32_t plo = extract32(b, pos), phi = extract32(b, pos + 32u);
 		const uint32_t pos2 = pos + 16u * ib - ns;
-		const uint64_t sec = ((uint64_t)extract32(b, pos2 + 32u) << 32) | extract32(b, pos2);
 		const bool two = ib2 != 0u, swap = two && isel != 0u;
+		const bool any_two = FIXED_MODE >= 0 ? (FIXED_MODE == 4 || FIXED_MODE == 5) : (__builtin_amdgcn_ballot_w64(two) != 0);
+		uint32_t slo = 0, shi = 0;
+		if (any_two) { slo = extract32(b, pos2); shi = extract32(b, pos2 + 32u); }
 		// colour uses the secondary indices when the index-selection bit is set (:374-375, 452-480)
 		const WeightParams wp_a = weight_params(ib), wp_b = weight_params(two ? ib2 : ib);
-		const uint32_t rotsel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u : (rot == 2u ? 0x01020300u : 0x02030100u));
+		// gather the high bytes of the four 16-bit sums; rotation swaps A with R/G/B (:497-508)
+		const uint32_t gather = rot == 0u ? 0x07050301u : (rot == 1u ? 0x01050307u : (rot == 2u ? 0x03050701u : 0x05070301u));
 
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
-			const uint32_t is_anchor = (amask >> i) & 1u;
-			const uint32_t off = (uint32_t)i * ib - (uint32_t)__builtin_popcount(amask & ((1u << i) - 1u));
-			const uint32_t idx_a = ubfe((uint32_t)(prim >> off), 0, ib - is_anchor);
-			const uint32_t off2 = ((uint32_t)i * ib2 - (i > 0 ? 1u : 0u)) & 63u;	// unused (garbage) when ib2 == 0
-			const uint32_t idx_b2 = ubfe((uint32_t)(sec >> off2), 0, (ib2 - (i == 0 ? 1u : 0u)) & 31u);
-			const uint32_t w_a = weight_of(idx_a, wp_a);
-			const uint32_t w_b = two ? weight_of(idx_b2, wp_b) : w_a;
-			const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
-
+			const uint32_t width = ib - ((amask >> i) & 1u);	// anchor texels store one bit less
+			const uint32_t w_a = weight_of(ubfe(plo, 0, width), wp_a);
+			plo = __builtin_amdgcn_alignbit(phi, plo, width);
+			phi >>= width;
+			uint32_t w_rg = DETEX_UMUL24(w_a, 0x00040004u), w_ba = w_rg;	// 4*w in both 16-bit lanes
+			if (any_two) {
+				const uint32_t width2 = (ib2 - (i == 0 ? 1u : 0u)) & 31u;
+				const uint32_t w_b = two ? weight_of(ubfe(slo, 0, width2), wp_b) : w_a;
+				slo = __builtin_amdgcn_alignbit(shi, slo, width2);
+				shi >>= width2;
+				const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
+				w_rg = DETEX_UMUL24(wc, 0x00040004u);
+				w_ba = (wc | (wal << 16)) << 2;
+			}
 			const uint32_t m1 = bit_to_mask(pword, 2 * i), m2 = bit_to_mask(pword, 2 * i + 1);
-			const uint32_t e0 = bfi(m2, ep[4], bfi(m1, ep[2], ep[0])), e1 = bfi(m2, ep[5], bfi(m1, ep[3], ep[1]));
-			// ((64-w)*e0 + w*e1 + 32) >> 6, R and B together in 16-bit lanes (:182-193)
-			const uint32_t rb2 = ((e0 & 0x00FF00FFu) * (64u - wc) + (e1 & 0x00FF00FFu) * wc + 0x00200020u) >> 6;
-			const uint32_t g = (((e0 >> 8) & 0xFFu) * (64u - wc) + ((e1 >> 8) & 0xFFu) * wc + 32u) >> 6;
-			const uint32_t a = ((e0 >> 24) * (64u - wal) + (e1 >> 24) * wal + 32u) >> 6;
-			const uint32_t px = (rb2 & 0x00FF00FFu) | (g << 8) | (a << 24);
-			d[i] = perm(px, px, rotsel);			// rotation swaps A with R/G/B (:497-508)
+			const uint32_t base_rg = bfi(m2, s2.base_rg, bfi(m1, s1.base_rg, s0.base_rg));
+			const uint32_t base_ba = bfi(m2, s2.base_ba, bfi(m1, s1.base_ba, s0.base_ba));
+			const uint32_t diff_rg = bfi(m2, s2.diff_rg, bfi(m1, s1.diff_rg, s0.diff_rg));
+			const uint32_t diff_ba = bfi(m2, s2.diff_ba, bfi(m1, s1.diff_ba, s0.diff_ba));
+			d[i] = perm(pk_mad_u16(diff_ba, w_ba, base_ba), pk_mad_u16(diff_rg, w_rg, base_rg), gather);
 		}
 		return true;
 	}
 };
+using DecBPTC = DecBPTCMode<-1>;
 
 }  // namespace detexhip

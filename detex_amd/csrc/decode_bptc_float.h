@@ -166,15 +166,16 @@ template <bool SIGNED> struct DecBPTCFloatT {
 		const uint32_t pmask = two ? (uint32_t)kPartition1Bit[part] : 0u;
 		const uint32_t amask = 1u | (two ? (1u << (kAnchorWords[part] & 0xFu)) : 0u);
 		const uint32_t ibits = two ? 3u : 4u;
-		const uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
-		const uint32_t hi = two ? (blk.w >> 18) : (blk.w >> 1);
-		const uint64_t stream = ((uint64_t)hi << 32) | lo;
+		// index stream consumed LSB-first as a {hi,lo} pair advanced by funnel shifts
+		uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
+		uint32_t hi = two ? (blk.w >> 18) : (blk.w >> 1);
 		const WeightParams wp = weight_params(ibits);
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
-			const uint32_t is_anchor = (amask >> i) & 1u;
-			const uint32_t off = (uint32_t)i * ibits - (uint32_t)__builtin_popcount(amask & ((1u << i) - 1u));
-			const int32_t w = (int32_t)weight_of(ubfe((uint32_t)(stream >> off), 0, ibits - is_anchor), wp);
+			const uint32_t width = ibits - ((amask >> i) & 1u);	// anchor texels store one bit less
+			const int32_t w = (int32_t)weight_of(ubfe(lo, 0, width), wp);
+			lo = __builtin_amdgcn_alignbit(hi, lo, width);
+			hi >>= width;
 			const uint32_t ms = bit_to_mask(pmask, i);
 			uint32_t h[3];
 #pragma unroll

@@ -41,6 +41,12 @@ DETEX_HD uint32_t bptc_weight(uint32_t index, uint32_t bits) {
 	return (((index << 6) + (d >> 1)) * magic) >> 16;
 }
 // signed-RGTC value map [-127,127] -> int16 (decompress-rgtc.c:125-126): (v+127)*65535/254 - 32768
+// 24-bit multiply (v_mul_u32_u24, full rate; a plain 32-bit '*' of unbounded operands is v_mul_lo_u32)
+#if defined(__HIPCC__)
+#define DETEX_UMUL24(a, b) __umul24((a), (b))
+#else
+#define DETEX_UMUL24(a, b) (((a) & 0xFFFFFFu) * ((b) & 0xFFFFFFu))
+#endif
 DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) { return (((uint32_t)(v + 127) * 65535u) / 254u - 32768u) & 0xFFFFu; }
 
 #if defined(DETEXHIP_DEVICE_CODE)
@@ -70,13 +76,13 @@ DH uint32_t spread3to8(uint32_t c) {
 
 // ---- 128-bit little-endian block viewed as four dwords -------------------------------------
 struct Bits128 { uint32_t w[4]; };
-// bits [pos, pos+32) of the block, pos in 0..127 per lane (bits beyond 127 read as 0).
-// Two funnel shifts over a dword pair selected by pos>>5: no dynamic register indexing.
+// bits [pos, pos+32) of the block for a per-lane pos in 0..127 (bits beyond 127 read as 0).
+// Straight-line: the dword pair is picked with two lane masks (v_bfe_i32) and five v_bfi_b32,
+// then one v_alignbit_b32 -- no dynamic register indexing, no exec-mask branches.
 DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
-	const uint32_t k = pos >> 5, s = pos & 31u;
-	const uint32_t lo = k == 0 ? b.w[0] : (k == 1 ? b.w[1] : (k == 2 ? b.w[2] : (k == 3 ? b.w[3] : 0u)));
-	const uint32_t hi = k == 0 ? b.w[1] : (k == 1 ? b.w[2] : (k == 2 ? b.w[3] : 0u));
-	return __builtin_amdgcn_alignbit(hi, lo, s);	// ({hi,lo} >> s)[31:0]
+	const uint32_t k0 = bit_to_mask(pos, 5), k1 = bit_to_mask(pos, 6);
+	const uint32_t x_lo = bfi(k1, b.w[2], b.w[0]), x_mid = bfi(k1, b.w[3], b.w[1]), x_hi = b.w[2] & ~k1;
+	return __builtin_amdgcn_alignbit(bfi(k0, x_hi, x_mid), bfi(k0, x_mid, x_lo), pos & 31u);
 }
 DH uint32_t extract_bits(const Bits128 &b, uint32_t pos, uint32_t n) { return ubfe(extract32(b, pos), 0, n); }
 #endif  // DETEXHIP_DEVICE_CODE

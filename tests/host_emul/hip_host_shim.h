@@ -43,3 +43,5 @@ static inline int32_t __mul24(int32_t a, int32_t b) {
 	const int32_t sa = (int32_t)((uint32_t)a << 8) >> 8, sb = (int32_t)((uint32_t)b << 8) >> 8;
 	return (int32_t)((int64_t)sa * sb);
 }
+// wave-uniform votes: the emulation runs one "lane" at a time, so a ballot is just the predicate
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }
