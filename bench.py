@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (include/detexhip.h)")
     ap.add_argument("--stream", default="U", choices=["U", "M"])
+    ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--gather", action="store_true", help="also time the optional whole-image all-gather (N>1)")
     ap.add_argument("--formats-json", default=None, help="also bench every format, write a table to this path")
@@ -140,12 +141,20 @@ def main():
             data = streams.stream_m(fmt, data)
         return data
 
+    TARGETS = {"BGRA8": F.PIXEL_FORMAT_BGRA8, "BGRX8": F.PIXEL_FORMAT_BGRX8, "RGB8": F.PIXEL_FORMAT_RGB8,
+               "FLOAT_BGRX16": F.PIXEL_FORMAT_FLOAT_BGRX16, "RGBA8": F.PIXEL_FORMAT_RGBA8}
+
+    def target_of(fmt):
+        pf = TARGETS[args.target] if args.target else F.native_pixel_format(fmt)
+        return pf, 1 + ((pf & 0xF00) >> 8)
+
     def run_format(fmt, W, H, steps, warmup):
         data = make_input(fmt, W, H, rank)
         d_blocks = torch.from_numpy(np.ascontiguousarray(data)).cuda()
-        d_out = torch.empty(W * H * fmt.pixel_bytes, dtype=torch.uint8, device="cuda")
+        pf, tpx = target_of(fmt)
+        d_out = torch.empty(W * H * tpx, dtype=torch.uint8, device="cuda")
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        step = lambda: binding.decompress_linear_device(fmt, d_blocks, W, H, out=d_out, status=status)
+        step = lambda: binding.decompress_linear_device(fmt, d_blocks, W, H, out=d_out, status=status, pixel_format=pf)
         for _ in range(warmup):
             step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,7 +177,8 @@ def main():
     W = H = args.size
     data, d_blocks, d_out, wall, launch_ms = run_format(fmt, W, H, args.steps, args.warmup)
     blocks = (W // 4) * (H // 4)
-    alg_bytes = blocks * (fmt.block_bytes + 16 * fmt.pixel_bytes)
+    pf, tpx = target_of(fmt)
+    alg_bytes = blocks * (fmt.block_bytes + 16 * tpx)
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
     gpix = world * W * H * args.steps / wall / 1e9
 
@@ -196,16 +206,17 @@ def main():
         "config": {"workload": "%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, "
                                "sharded by block rows: one %d-row band per GPU" % (fmt.name, F.target_name(fmt), W, H, args.stream, H),
                    "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": blocks,
-                   "kernel": binding.kernel_name(fmt), "variant": args.variant},
+                   "kernel": binding.kernel_name(fmt), "variant": args.variant, "target_pixel_format": "0x%04X" % pf},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
-                     "write_frac": round(blocks * 16 * fmt.pixel_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "write_frac": round(blocks * 16 * tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            t = json.load(open(pmc)).get("%s/%d/v%d" % (fmt.name, W, args.variant))
+            key = "%s/%d/v%d" % (fmt.name, W, args.variant) + ("/%s" % args.target if args.target else "")
+            t = json.load(open(pmc)).get(key)
             if t:
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = t.get("source")
@@ -218,7 +229,7 @@ def main():
         # bit-exactness of what was just timed, against the CPU checker on a bounded sample (first 64 block rows)
         rows = 64
         orc = ol.Oracle()
-        ok_o, want = orc.linear(fmt, data[:rows * (W // 4) * fmt.block_bytes], W, rows * 4)
+        ok_o, want = orc.linear_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W, rows * 4, pf)
         got = d_out[:want.size].cpu().numpy()
         result["verified_bit_exact_rows"] = rows * 4 if np.array_equal(got, want) else 0
         if not np.array_equal(got, want):
@@ -227,9 +238,9 @@ def main():
         # host-pointer drop-in tier (PCIe-inclusive; never `value`)
         try:
             api = ol.DetexAPI(binding.LIB_PATH)
-            host_out = np.empty(W * H * fmt.pixel_bytes, np.uint8)
-            api.linear(fmt, data, W, H, out=host_out)
-            t0 = time.perf_counter(); api.linear(fmt, data, W, H, out=host_out); th = time.perf_counter() - t0
+            host_out = np.empty(W * H * tpx, np.uint8)
+            api.linear(fmt, data, W, H, out=host_out, pixel_format=pf)
+            t0 = time.perf_counter(); api.linear(fmt, data, W, H, out=host_out, pixel_format=pf); th = time.perf_counter() - t0
             result["host_tier"] = {"gpixel_s_pcie_inclusive": round(W * H / th / 1e9, 3), "ms": round(th * 1e3, 2)}
         except Exception as e:  # noqa
             log("host tier timing failed:", e)
@@ -241,6 +252,7 @@ def main():
         for f in F.FORMATS:
             for kind in (["U", "M"] if f.name in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT") else ["U"]):
                 args.stream = kind
+                args.target = None
                 _, _, _, w_, ms_ = run_format(f, W, H, max(20, args.steps // 4), 5)
                 ab = blocks * (f.block_bytes + 16 * f.pixel_bytes)
                 table["%s/%s" % (f.name, kind)] = {"launch_us": round(ms_ * 1e3, 2), "gpixel_s": round(W * H / (ms_ * 1e-3) / 1e9, 1),

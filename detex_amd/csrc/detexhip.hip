@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #define DETEXHIP_BUILDING_LIBRARY 1
 #include "../../include/detex.h"
@@ -57,49 +58,83 @@ namespace {
 
 struct Geometry {
 	const void *blocks; void *pixels; uint32_t wb, hb, width, height; uint64_t pitch;
-	uint32_t *status; hipStream_t stream; int variant;
+	uint32_t *status; hipStream_t stream; int variant; int epi;
 };
 struct BatchArgs {
 	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
-	hipStream_t stream; bool checked;
+	hipStream_t stream; bool checked; int epi;
 };
 
-template <class Dec> bool fast_geometry(const Geometry &g) {
-	return (g.width & 3u) == 0 && (g.height & 3u) == 0 && g.wb * 4u == g.width && g.hb * 4u == g.height &&
-		(reinterpret_cast<uintptr_t>(g.pixels) & 15u) == 0 && (g.pitch & 15u) == 0 &&
-		(Dec::kPixelBytes >= 4 || ((g.pitch % (4u * Dec::kPixelBytes)) == 0));
+// which in-kernel pixel-format epilogues a decoder supports: the RGBA8-class
+// formats take BGRA8/BGRX8 and RGB8 targets, unsigned BC6H takes FLOAT_BGRX16
+template <class Dec> constexpr int target_class() {
+	if (std::is_same_v<Dec, DecBC1> || std::is_same_v<Dec, DecBC1A> || std::is_same_v<Dec, DecBC2> || std::is_same_v<Dec, DecBC3> ||
+			std::is_same_v<Dec, DecBPTC> || std::is_same_v<Dec, DecETC1> || std::is_same_v<Dec, DecETC2> ||
+			std::is_same_v<Dec, DecETC2Punchthrough> || std::is_same_v<Dec, DecETC2EAC>)
+		return 1;
+	if (std::is_same_v<Dec, DecBPTCFloat>) return 2;
+	return 0;
 }
 
-template <class Dec> hipError_t launch_linear(const Geometry &g) {
+template <class Dec, int EPI> bool fast_geometry(const Geometry &g) {
+	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr unsigned align = row_bytes % 16u == 0 ? 16u : (row_bytes % 8u == 0 ? 8u : 4u);
+	return (g.width & 3u) == 0 && (g.height & 3u) == 0 && g.wb * 4u == g.width && g.hb * 4u == g.height &&
+		(reinterpret_cast<uintptr_t>(g.pixels) % align) == 0 && (g.pitch % align) == 0;
+}
+
+template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 	const uint32_t n = g.wb * g.hb;
-	if (n == 0) return hipSuccess;
 	const dim3 grid((n + 255u) / 256u), block(256);
 	uint8_t *px = static_cast<uint8_t *>(g.pixels);
-	if (fast_geometry<Dec>(g)) {
-		if (g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0)
+	if (fast_geometry<Dec, EPI>(g)) {
+		if (EPI == kEpiNone && g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0)
 			return Tile4x4<Dec>::launch(g.blocks, px, g.wb, g.hb, g.pitch, g.status, g.stream);
-		if (g.variant != 2)	// default: non-temporal row stores (measured 43 vs 51 us on BC1 8192^2)
-			hipLaunchKernelGGL((decode_linear<Dec, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+		if (EPI != kEpiNone || g.variant != 2)	// default: non-temporal row stores (43 vs 51 us on BC1 8192^2)
+			hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 		else
-			hipLaunchKernelGGL((decode_linear<Dec, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			hipLaunchKernelGGL((decode_linear<Dec, kEpiNone, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 	} else {
-		hipLaunchKernelGGL((decode_linear_clipped<Dec>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.width,
+		hipLaunchKernelGGL((decode_linear_clipped<Dec, EPI>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.width,
 			g.height, g.pitch, g.status);
 	}
 	return hipGetLastError();
 }
 
-template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
-	if (a.n == 0) return hipSuccess;
+template <class Dec> hipError_t launch_linear(const Geometry &g) {
+	if (g.wb * g.hb == 0) return hipSuccess;
+	if constexpr (target_class<Dec>() == 1) {
+		if (g.epi == kEpiSwapRB8) return launch_linear_epi<Dec, kEpiSwapRB8>(g);
+		if (g.epi == kEpiPackRGB8) return launch_linear_epi<Dec, kEpiPackRGB8>(g);
+	}
+	if constexpr (target_class<Dec>() == 2) {
+		if (g.epi == kEpiSwapRB16) return launch_linear_epi<Dec, kEpiSwapRB16>(g);
+	}
+	return g.epi == kEpiNone ? launch_linear_epi<Dec, kEpiNone>(g) : hipErrorInvalidValue;
+}
+
+template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 	const dim3 grid((unsigned)((a.n + 255u) / 256u)), block(256);
 	uint8_t *px = static_cast<uint8_t *>(a.pixels);
 	if (a.checked)
-		hipLaunchKernelGGL((decode_blocks<Dec, true>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		hipLaunchKernelGGL((decode_blocks<Dec, EPI, true>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	else
-		hipLaunchKernelGGL((decode_blocks<Dec, false>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		hipLaunchKernelGGL((decode_blocks<Dec, EPI, false>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	return hipGetLastError();
+}
+
+template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
+	if (a.n == 0) return hipSuccess;
+	if constexpr (target_class<Dec>() == 1) {
+		if (a.epi == kEpiSwapRB8) return launch_blocks_epi<Dec, kEpiSwapRB8>(a);
+		if (a.epi == kEpiPackRGB8) return launch_blocks_epi<Dec, kEpiPackRGB8>(a);
+	}
+	if constexpr (target_class<Dec>() == 2) {
+		if (a.epi == kEpiSwapRB16) return launch_blocks_epi<Dec, kEpiSwapRB16>(a);
+	}
+	return a.epi == kEpiNone ? launch_blocks_epi<Dec, kEpiNone>(a) : hipErrorInvalidValue;
 }
 
 struct FormatEntry {
@@ -128,13 +163,25 @@ const FormatEntry *lookup_format(uint32_t texture_format) {
 	return kFormats[idx].texture_format == texture_format ? &kFormats[idx] : nullptr;
 }
 
-// accepted targets: native, or the RGBX8 <-> RGBA8 no-op edge (convert.c:768-769, 1087-1092)
-bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) {
+// Target pixel formats of the block-decode path and the epilogue that produces each (-1 = not
+// offered).  Native, the RGBX8 <-> RGBA8 no-op edge (convert.c:768-769, 1087-1092), and the
+// in-kernel epilogues of SURVEY.md 8f-2: BGRA8/BGRX8 (what validate.c:204-209 and detex-view.c
+// request), RGB8 (detex-convert.c:283-284) for the RGBA8-class formats; FLOAT_BGRX16 for BC6H.
+// Semantics checked against the compiled reference (tools/make_goldens.py).
+enum : uint32_t { kPixelBGRA8 = 0x33C, kPixelBGRX8 = 0x328, kPixelRGB8 = 0x220, kPixelFloatBGRX16 = 0x2729 };
+int epilogue_for(uint32_t texture_format, uint32_t pixel_format) {
 	const uint32_t native = texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK;
-	if (pixel_format == native) return true;
+	if (pixel_format == native) return kEpiNone;
 	const bool n8 = native == DETEX_PIXEL_FORMAT_RGBA8 || native == DETEX_PIXEL_FORMAT_RGBX8;
-	return n8 && (pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8);
+	if (n8) {
+		if (pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8) return kEpiNone;
+		if (pixel_format == kPixelBGRA8 || pixel_format == kPixelBGRX8) return kEpiSwapRB8;
+		if (pixel_format == kPixelRGB8) return kEpiPackRGB8;
+	}
+	if (native == DETEX_PIXEL_FORMAT_FLOAT_RGBX16 && pixel_format == kPixelFloatBGRX16) return kEpiSwapRB16;
+	return -1;
 }
+bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) { return epilogue_for(texture_format, pixel_format) >= 0; }
 
 // ------------------------------------------------------------------------------------------------
 // per-thread device context: stream + grow-only staging buffers for the host-pointer tier
@@ -199,18 +246,18 @@ bool reserve(void **buf, size_t *cap, size_t need) {
 // shared by the 19 leaf functions and detexDecompressBlock: one block through the GPU.
 // Returns 1 = decoded, 0 = the decoder returned false, -1 = HIP/runtime failure (message set).
 int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags,
-		uint8_t *pixel_buffer) {
+		uint8_t *pixel_buffer, uint32_t pixel_format) {
 	if (!context_ready()) return -1;
 	ThreadContext &c = t_ctx;
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
-	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(f->texture_format);
+	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
 	if (!reserve(&c.d_in, &c.in_cap, 4096) || !reserve(&c.d_out, &c.out_cap, 4096)) return -1;
 	uint8_t *d_ok = reinterpret_cast<uint8_t *>(c.d_status + 1);
 	uint8_t host_out[DETEX_MAX_BLOCK_SIZE];
 	uint8_t ok = 0;
 	auto run = [&]() -> bool {
 		HIP_TRY(hipMemcpyAsync(c.d_in, bitstring, bs, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
-		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true };
+		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true, epilogue_for(f->texture_format, pixel_format) };
 		HIP_TRY(f->blocks(a), "kernel launch");
 		HIP_TRY(hipMemcpyAsync(host_out, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 		HIP_TRY(hipMemcpyAsync(&ok, d_ok, 1, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
@@ -266,25 +313,26 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 		return 1;
 	}
 	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	const size_t palign = px == 3 ? 1 : (px < 4 ? px : 4);	// 24-bit pixels are byte-addressed, 64-bit ones dword-addressed
 	if (width < 0 || height < 0 || width_in_blocks < 0 || height_in_blocks < 0 || pitch_bytes < (size_t)width * px ||
-			(pitch_bytes % px) != 0 || (reinterpret_cast<uintptr_t>(d_pixels) % px) != 0 ||
+			(pitch_bytes % palign) != 0 || (reinterpret_cast<uintptr_t>(d_pixels) % palign) != 0 ||
 			(uint64_t)width_in_blocks * (uint64_t)height_in_blocks > 0xFFFFFF00ull) {
 		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: bad geometry %dx%d (%dx%d blocks, pitch %zu)", width, height, width_in_blocks, height_in_blocks, pitch_bytes);
 		return 1;
 	}
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
-		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant() };
+		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epilogue_for(texture_format, pixel_format) };
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
 }
 
 static int blocks_device(const char *who, uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,
-		uint32_t flags, void *d_pixels, uint8_t *d_ok, uint32_t *d_status, void *stream, bool checked) {
+		uint32_t flags, void *d_pixels, uint8_t *d_ok, uint32_t *d_status, void *stream, bool checked, int epi) {
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
 	if (n_blocks > 0xFFFFFF00ull) { detexSetErrorMessage("%s: too many blocks", who); return 1; }
-	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, flags, d_ok, d_status, static_cast<hipStream_t>(stream), checked };
+	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, flags, d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi };
 	hipError_t e = f->blocks(a);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -298,13 +346,14 @@ extern "C" int detexhipDecompressTextureTiledDevice(uint32_t texture_format, con
 	}
 	if (width_in_blocks < 0 || height_in_blocks < 0) { detexSetErrorMessage("detexhipDecompressTextureTiledDevice: bad geometry"); return 1; }
 	return blocks_device("detexhipDecompressTextureTiledDevice", texture_format, d_blocks,
-		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false);
+		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false,
+		epilogue_for(texture_format, pixel_format));
 }
 
 extern "C" int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,
 		uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream) {
 	return blocks_device("detexhipDecompressBlocksDevice", texture_format, d_blocks, n_blocks, mode_mask, flags, d_pixels, d_ok,
-		nullptr, stream, true);
+		nullptr, stream, true, kEpiNone);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,7 +363,7 @@ extern "C" int detexhipDecompressBlocksDevice(uint32_t texture_format, const voi
 	extern "C" bool detexDecompressBlock##NAME(const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags, \
 			uint8_t *pixel_buffer) {                                                                         \
 		return decode_one_block(&kFormats[DETEX_TEXTURE_FORMAT_##NAME >> 24], bitstring, mode_mask, flags,  \
-			pixel_buffer) == 1;                                                                              \
+			pixel_buffer, DETEX_TEXTURE_FORMAT_##NAME & 0xFFFFu) == 1;                                       \
 	}
 LEAF(BC1) LEAF(BC1A) LEAF(BC2) LEAF(BC3) LEAF(RGTC1) LEAF(SIGNED_RGTC1) LEAF(RGTC2) LEAF(SIGNED_RGTC2)
 LEAF(BPTC_FLOAT) LEAF(BPTC_SIGNED_FLOAT) LEAF(BPTC) LEAF(ETC1) LEAF(ETC2) LEAF(ETC2_PUNCHTHROUGH) LEAF(ETC2_EAC)
@@ -334,7 +383,7 @@ extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_
 			"block-decode path of libdetexhip", texture_format, pixel_format);
 		return false;
 	}
-	const int r = decode_one_block(f, bitstring, mode_mask, flags, pixel_buffer);
+	const int r = decode_one_block(f, bitstring, mode_mask, flags, pixel_buffer, pixel_format);
 	if (r == 0)	// same text as the reference (texture.c:63-64); HIP failures have set their own message
 		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture_format);
 	return r == 1;

@@ -4,11 +4,14 @@
 // blocks of the row-major block stream, a 256-thread workgroup 256 of them.
 //   load   lane i reads block i: 64 lanes x 8/16 B = one 512 B / 1 KiB fully coalesced
 //          global_load_dwordx2/x4 per wave, no LDS needed because nothing is shared
-//   decode 16 texels in registers (4*P dwords, P = bytes per pixel)
-//   store  linear layout: texel row r of the 64 blocks is 64 x 4P contiguous bytes of image
-//          row 4*by+r  ->  four (P=8: eight) wave-wide global_store_dwordx4, each a single
-//          1 KiB contiguous run (full 128 B lines, no partial-line writes, no read-for-ownership)
-//          tiled layout: each lane owns 16*P contiguous bytes
+//   decode 16 texels in registers (4*P dwords, P = bytes per native pixel)
+//   epilogue (optional, section 8f-2): in-register pixel-format conversion of the decoded block
+//          (R<->B swizzle, RGBX8 -> packed RGB8) -- free at HBM rate, no second pass over the image
+//   store  linear layout: texel row r of the 64 blocks is 64 x 4T contiguous bytes of image
+//          row 4*by+r (T = bytes per target pixel)  ->  four (T=8: eight) wave-wide
+//          non-temporal stores, each a single 0.75-2 KiB contiguous run (full 128 B lines,
+//          no partial-line writes, no read-for-ownership)
+//          tiled layout: each lane owns 16*T contiguous bytes
 // Invalid blocks are zero-filled and raise *status (texture.c:125-128 semantics): one relaxed
 // agent-scope load + (only while it still reads 0) one store per wave, never an atomic RMW.
 #pragma once
@@ -20,24 +23,70 @@ template <int BYTES> struct BlockWord;
 template <> struct BlockWord<8> { using type = uint2; };
 template <> struct BlockWord<16> { using type = uint4; };
 
-template <int P> struct RowWord;			// 4 pixels of P bytes
-template <> struct RowWord<1> { using type = uint32_t; };
-template <> struct RowWord<2> { using type = uint2; };
-template <> struct RowWord<4> { using type = uint4; };
+// ---- in-register pixel-format epilogues (reference: convert.c:37-52, 54-70, 671-684) ----------
+enum : int {
+	kEpiNone = 0,		// native pixel format (or the RGBX8 <-> RGBA8 no-op, convert.c:768-769)
+	kEpiSwapRB8 = 1,	// RGBA8/RGBX8 -> BGRA8/BGRX8: swap bytes 0 and 2, keep byte 3 (convert.c:37-52)
+	kEpiPackRGB8 = 2,	// RGBA8/RGBX8 -> RGB8: drop byte 3, 4 pixels -> 3 dwords (convert.c:671-684)
+	kEpiSwapRB16 = 3,	// FLOAT_RGBX16 -> FLOAT_BGRX16: swap halves 0 and 2 (convert.c:54-70)
+};
+template <int EPI, int P> struct Epilogue;
+template <int P> struct Epilogue<kEpiNone, P> {
+	static constexpr int kRowDwords = P;		// dwords per 4-pixel row of the target
+	static DH void apply(const uint32_t (&d)[4 * P], uint32_t (&o)[4 * P]) {
+#pragma unroll
+		for (int k = 0; k < 4 * P; k++) o[k] = d[k];
+	}
+};
+template <> struct Epilogue<kEpiSwapRB8, 4> {
+	static constexpr int kRowDwords = 4;
+	static DH void apply(const uint32_t (&d)[16], uint32_t (&o)[16]) {
+#pragma unroll
+		for (int k = 0; k < 16; k++) o[k] = perm(d[k], d[k], 0x03000102u);
+	}
+};
+template <> struct Epilogue<kEpiPackRGB8, 4> {
+	static constexpr int kRowDwords = 3;
+	static DH void apply(const uint32_t (&d)[16], uint32_t (&o)[12]) {
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			o[3 * r + 0] = perm(d[4 * r + 1], d[4 * r + 0], 0x04020100u);	// R0 G0 B0 R1
+			o[3 * r + 1] = perm(d[4 * r + 2], d[4 * r + 1], 0x05040201u);	// G1 B1 R2 G2
+			o[3 * r + 2] = perm(d[4 * r + 3], d[4 * r + 2], 0x06050402u);	// B2 R3 G3 B3
+		}
+	}
+};
+template <> struct Epilogue<kEpiSwapRB16, 8> {
+	static constexpr int kRowDwords = 8;
+	static DH void apply(const uint32_t (&d)[32], uint32_t (&o)[32]) {
+#pragma unroll
+		for (int k = 0; k < 16; k++) {			// pixel = {R|G<<16, B|X<<16}
+			o[2 * k] = perm(d[2 * k + 1], d[2 * k], 0x03020504u);	// B, G
+			o[2 * k + 1] = perm(d[2 * k + 1], d[2 * k], 0x07060100u);	// R, X
+		}
+	}
+};
 
-template <int P, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
-	if constexpr (P == 1) {
+// one 4-pixel row of ROW dwords; non-temporal (streaming) or ordinary stores
+template <int ROW, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
+	if constexpr (ROW == 1) {
 		if (NT) __builtin_nontemporal_store(d[0], reinterpret_cast<uint32_t *>(dst));
 		else *reinterpret_cast<uint32_t *>(dst) = d[0];
-	} else if constexpr (P == 2) {
+	} else if constexpr (ROW == 2) {
 		typedef uint32_t v2 __attribute__((ext_vector_type(2)));
 		v2 v = { d[0], d[1] };
 		if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2 *>(dst));
 		else *reinterpret_cast<v2 *>(dst) = v;
+	} else if constexpr (ROW == 3) {
+		typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+		typedef v3 v3_unaligned __attribute__((aligned(4)));
+		v3 v = { d[0], d[1], d[2] };
+		if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v3_unaligned *>(dst));
+		else *reinterpret_cast<v3_unaligned *>(dst) = v;
 	} else {
 		typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-		for (int k = 0; k < P / 4; k++) {
+		for (int k = 0; k < ROW / 4; k++) {
 			v4 v = { d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] };
 			if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(dst) + k);
 			else reinterpret_cast<v4 *>(dst)[k] = v;
@@ -53,77 +102,12 @@ DH void raise_status(bool bad, uint32_t *status) {
 		__hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- linear layout, fast path: width % 4 == 0, 16-byte aligned rows ---------------------------
-template <class Dec, bool NT>
-__global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ blocks,
-		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
-		uint32_t *__restrict__ status) {
+// decode + zero-fill on failure + epilogue; returns ok
+template <class Dec, int EPI, bool CHECKED>
+DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
+		uint32_t (&o)[4 * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords]) {
 	constexpr int P = Dec::kPixelBytes;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_blocks) return;
-	const Word blk = reinterpret_cast<const Word *>(blocks)[i];
-	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
-	uint32_t d[4 * P];
-	const bool ok = Dec::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-	if (!ok) {
-#pragma unroll
-		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
-	}
-	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * P);
-#pragma unroll
-	for (int r = 0; r < 4; r++) store_row<P, NT>(dst + (uint64_t)r * pitch, d + r * P);
-	raise_status(!ok, status);
-}
-
-// ---- linear layout, clipped / unaligned path (texture.c:116-120,132-136) ----------------------
-// Any width/height/pitch/pointer alignment down to the pixel size; texels outside the image
-// are dropped.  Per-pixel stores: this path is for edge geometry, not for throughput.
-template <int P> DH void store_pixel(uint8_t *dst, const uint32_t *row, int x) {
-	if constexpr (P == 1) *dst = (uint8_t)(row[0] >> (8 * x));
-	else if constexpr (P == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(row[x >> 1] >> (16 * (x & 1)));
-	else if constexpr (P == 4) *reinterpret_cast<uint32_t *>(dst) = row[x];
-	else { reinterpret_cast<uint32_t *>(dst)[0] = row[2 * x]; reinterpret_cast<uint32_t *>(dst)[1] = row[2 * x + 1]; }
-}
-
-template <class Dec>
-__global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
-		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
-		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
-	constexpr int P = Dec::kPixelBytes;
-	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_blocks) return;
-	const Word blk = reinterpret_cast<const Word *>(blocks)[i];
-	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
-	uint32_t d[4 * P];
-	const bool ok = Dec::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-	if (!ok) {
-#pragma unroll
-		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
-	}
-#pragma unroll
-	for (int r = 0; r < 4; r++) {
-		const uint32_t y = by * 4u + r;
-		if (y >= height) continue;
-		uint8_t *dst = pixels + (uint64_t)y * pitch + (uint64_t)bx * (4u * P);
-#pragma unroll
-		for (int x = 0; x < 4; x++)
-			if (bx * 4u + x < width) store_pixel<P>(dst + x * P, d + r * P, x);
-	}
-	raise_status(!ok, status);
-}
-
-// ---- block-major output (detexDecompressTextureTiled, texture.c:77-98) and the batched form of
-// the per-block API (mode_mask / flags honoured, per-block ok byte) ----------------------------
-template <class Dec, bool CHECKED>
-__global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ blocks,
-		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
-		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
-	constexpr int P = Dec::kPixelBytes;
-	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_blocks) return;
 	const Word blk = reinterpret_cast<const Word *>(blocks)[i];
 	uint32_t d[4 * P];
 	const bool ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
@@ -131,14 +115,78 @@ __global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ bl
 #pragma unroll
 		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
 	}
-	uint32_t *dst = reinterpret_cast<uint32_t *>(pixels + (uint64_t)i * (16u * P));
-	if constexpr (P >= 4) {
+	Epilogue<EPI, P>::apply(d, o);
+	return ok;
+}
+
+// ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
+template <class Dec, int EPI, bool NT>
+__global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ blocks,
+		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
+		uint32_t *__restrict__ status) {
+	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_blocks) return;
+	uint32_t o[4 * ROW];
+	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
+	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
+#pragma unroll
+	for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
+	raise_status(!ok, status);
+}
+
+// ---- linear layout, clipped / unaligned path (texture.c:116-120,132-136) ----------------------
+// Any width/height/pitch/pointer alignment down to the pixel size; texels outside the image
+// are dropped.  Per-pixel stores: this path is for edge geometry, not for throughput.
+template <int ROW> DH void store_pixel(uint8_t *dst, const uint32_t *row, int x) {
+	if constexpr (ROW == 1) *dst = (uint8_t)(row[0] >> (8 * x));
+	else if constexpr (ROW == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(row[x >> 1] >> (16 * (x & 1)));
+	else if constexpr (ROW == 3) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) dst[k] = (uint8_t)(row[(3 * x + k) >> 2] >> (8 * ((3 * x + k) & 3)));
+	} else if constexpr (ROW == 4) *reinterpret_cast<uint32_t *>(dst) = row[x];
+	else { reinterpret_cast<uint32_t *>(dst)[0] = row[2 * x]; reinterpret_cast<uint32_t *>(dst)[1] = row[2 * x + 1]; }
+}
+
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
+		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
+		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
+	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_blocks) return;
+	uint32_t o[4 * ROW];
+	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint32_t y = by * 4u + r;
+		if (y >= height) continue;
+		uint8_t *dst = pixels + (uint64_t)y * pitch + (uint64_t)bx * (4u * ROW);
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			if (bx * 4u + x < width) store_pixel<ROW>(dst + x * ROW, o + r * ROW, x);
+	}
+	raise_status(!ok, status);
+}
+
+// ---- block-major output (detexDecompressTextureTiled, texture.c:77-98) and the batched form of
+// the per-block API (mode_mask / flags honoured, per-block ok byte) ----------------------------
+template <class Dec, int EPI, bool CHECKED>
+__global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ blocks,
+		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
+		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
+	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_blocks) return;
+	uint32_t o[4 * ROW];
+	const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(pixels + (uint64_t)i * (16u * ROW));
+	if constexpr ((4 * ROW) % 4 == 0) {
 		typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-		for (int k = 0; k < P; k++) reinterpret_cast<v4 *>(dst)[k] = v4{ d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] };
-	} else {
-#pragma unroll
-		for (int k = 0; k < 4 * P; k++) dst[k] = d[k];
+		for (int k = 0; k < ROW; k++) reinterpret_cast<v4 *>(dst)[k] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
 	}
 	if (ok_out) ok_out[i] = ok ? 1 : 0;
 	raise_status(!ok, status);

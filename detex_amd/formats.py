@@ -75,10 +75,33 @@ def target_name(fmt):
     return _PIXEL_NAMES[native_pixel_format(fmt)]
 
 
+PIXEL_FORMAT_BGRA8 = 0x33C
+PIXEL_FORMAT_BGRX8 = 0x328
+PIXEL_FORMAT_RGB8 = 0x220
+PIXEL_FORMAT_FLOAT_BGRX16 = 0x2729
+
+# epilogue kinds (detex_amd/csrc/kernels.h, oracle orc_convert_pixels): 0 none, 1 swap R/B (8-bit),
+# 2 pack RGB8, 3 swap R/B (16-bit)
+def epilogue_kind(fmt, pixel_format):
+    n = native_pixel_format(fmt)
+    if pixel_format == n:
+        return 0
+    if n in (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8):
+        return {PIXEL_FORMAT_RGBA8: 0, PIXEL_FORMAT_RGBX8: 0, PIXEL_FORMAT_BGRA8: 1, PIXEL_FORMAT_BGRX8: 1,
+                PIXEL_FORMAT_RGB8: 2}.get(pixel_format)
+    if n == PIXEL_FORMAT_FLOAT_RGBX16 and pixel_format == PIXEL_FORMAT_FLOAT_BGRX16:
+        return 3
+    return None
+
+
 def accepted_pixel_formats(fmt):
-    """Target pixel formats the block-decode path supports for ``fmt``: the native one, plus
-    the RGBX8<->RGBA8 no-op edge of the reference's conversion table (convert.c:768-769)."""
+    """Target pixel formats the block-decode path supports for ``fmt``: the native one, the
+    RGBX8<->RGBA8 no-op edge of the reference's conversion table (convert.c:768-769), and the
+    in-kernel epilogues: BGRA8/BGRX8/RGB8 for RGBA8-class formats, FLOAT_BGRX16
+    for unsigned BC6H."""
     n = native_pixel_format(fmt)
     if n in (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8):
-        return (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8)
+        return (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8, PIXEL_FORMAT_BGRA8, PIXEL_FORMAT_BGRX8, PIXEL_FORMAT_RGB8)
+    if n == PIXEL_FORMAT_FLOAT_RGBX16:
+        return (n, PIXEL_FORMAT_FLOAT_BGRX16)
     return (n,)

@@ -782,3 +782,21 @@ uint64_t orc_fnv1a64(const uint8_t *p, size_t n) {
 	for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
 	return h;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The pixel-format conversions the GPU path offers as in-kernel epilogues.
+ * Semantics of the reference's converters: R<->B swap keeps the 4th component
+ * (convert.c:37-52 for 8-bit, :54-70 for 16-bit), RGBX8 -> RGB8 drops it (convert.c:671-684).
+ * ---------------------------------------------------------------------------------------- */
+long orc_convert_pixels(int kind, const uint8_t *in, long n_pixels, uint8_t *out) {
+	for (long i = 0; i < n_pixels; i++) {
+		switch (kind) {
+		case 1: out[4 * i] = in[4 * i + 2]; out[4 * i + 1] = in[4 * i + 1]; out[4 * i + 2] = in[4 * i]; out[4 * i + 3] = in[4 * i + 3]; break;
+		case 2: out[3 * i] = in[4 * i]; out[3 * i + 1] = in[4 * i + 1]; out[3 * i + 2] = in[4 * i + 2]; break;
+		case 3: memcpy(out + 8 * i, in + 8 * i + 4, 2); memcpy(out + 8 * i + 2, in + 8 * i + 2, 2);
+			memcpy(out + 8 * i + 4, in + 8 * i, 2); memcpy(out + 8 * i + 6, in + 8 * i + 6, 2); break;
+		default: return -1;
+		}
+	}
+	return n_pixels * (kind == 2 ? 3 : (kind == 3 ? 8 : 4));
+}

@@ -54,6 +54,29 @@ class Oracle:
         ok = self.lib.orc_decompress_tiled(fmt.index, _ptr(data), wb, hb, _ptr(out))
         return bool(ok), out
 
+    def convert(self, fmt, native_pixels, pixel_format):
+        """native pixels -> one of the target formats the GPU path offers as an epilogue"""
+        from detex_amd import formats as F
+        kind = F.epilogue_kind(fmt, pixel_format)
+        assert kind is not None, "target 0x%X not offered for %s" % (pixel_format, fmt.name)
+        native_pixels = np.ascontiguousarray(native_pixels, np.uint8).reshape(-1)
+        if kind == 0:
+            return native_pixels
+        n = native_pixels.size // fmt.pixel_bytes
+        out = np.zeros(n * (3 if kind == 2 else fmt.pixel_bytes), np.uint8)
+        self.lib.orc_convert_pixels.restype = ctypes.c_long
+        self.lib.orc_convert_pixels.argtypes = [ctypes.c_int, _u8p, ctypes.c_long, _u8p]
+        assert self.lib.orc_convert_pixels(kind, _ptr(native_pixels), n, _ptr(out)) == out.size
+        return out
+
+    def linear_to(self, fmt, data, width, height, pixel_format):
+        ok, out = self.linear(fmt, data, width, height)
+        return ok, self.convert(fmt, out, pixel_format)
+
+    def tiled_to(self, fmt, data, wb, hb, pixel_format):
+        ok, out = self.tiled(fmt, data, wb, hb)
+        return ok, self.convert(fmt, out, pixel_format)
+
     def modes(self, fmt, data):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         n = data.size // fmt.block_bytes

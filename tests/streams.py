@@ -10,6 +10,7 @@ from detex_amd import formats as F
 N_PER_CLASS = 256
 
 CLIP_SIZES = [(1, 1), (2, 3), (5, 9), (10, 6), (7, 13), (16, 4), (33, 17), (64, 64), (100, 36)]
+CLIP_SIZES_CONVERTED = [(5, 9), (16, 4), (33, 17), (100, 36)]     # also decoded into the epilogue targets
 
 # (mode_mask, flags) combinations exercised through the per-block API
 MASK_FLAG_MATRIX = [

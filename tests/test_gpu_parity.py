@@ -44,17 +44,17 @@ def test_fixture_host_api(fmt, hiplib, golden_json, oracle):
     from detex_amd.ktx import read_ktx
     k = read_ktx(os.path.join(os.path.dirname(__file__), "golden", fmt.fixture))
     want = golden_json("fixtures.json")[fmt.name]
-    for pf in F.accepted_pixel_formats(fmt):
+    for pf in F.accepted_pixel_formats(fmt):     # native, RGBX8<->RGBA8 and the in-kernel epilogue targets
         ok, out = hiplib.linear(fmt, k["data"], k["width"], k["height"], pixel_format=pf)
         g = want["0x%04X" % pf]
         assert ok == g["ok"]
         assert out.size == g["bytes"]
-        assert sha(out) == g["sha256"], fmt.name
-    ok_o, out_o = oracle.linear(fmt, k["data"], 64, 64)
-    assert np.array_equal(out, out_o)
-    ok_t, out_t = hiplib.tiled(fmt, k["data"], 16, 16)
-    ok_ot, out_ot = oracle.tiled(fmt, k["data"], 16, 16)
-    assert ok_t == ok_ot and np.array_equal(out_t, out_ot)
+        assert sha(out) == g["sha256"], (fmt.name, hex(pf))
+        ok_o, out_o = oracle.linear_to(fmt, k["data"], 64, 64, pf)
+        assert np.array_equal(out, out_o)
+        ok_t, out_t = hiplib.tiled(fmt, k["data"], 16, 16, pixel_format=pf)
+        ok_ot, out_ot = oracle.tiled_to(fmt, k["data"], 16, 16, pf)
+        assert ok_t == ok_ot and np.array_equal(out_t, out_ot), (fmt.name, hex(pf))
 
 
 # ---- (ii) mode-forced vectors: every mode / invalid class, per-block results + ok flags ----------
@@ -139,6 +139,23 @@ def test_clipped_sizes(fmt, hiplib, torch_cuda, forced_vectors, clip_vectors):
         assert np.array_equal(got[:, :w * px].reshape(-1), want), (fmt.name, w, h, "device pitch")
         assert (got[:, w * px:] == 0xA5).all(), (fmt.name, w, h, "wrote outside the image")
         assert bool(status.item() == 0) == want_ok
+        if (w, h) in streams.CLIP_SIZES_CONVERTED:      # the same clipped geometry into the epilogue targets
+            for pf in F.accepted_pixel_formats(fmt):
+                if not F.epilogue_kind(fmt, pf):
+                    continue
+                want_c = clip_vectors["%s/%dx%d/pf%04X" % (fmt.name, w, h, pf)]
+                ok, out = hiplib.linear(fmt, data, w, h, pixel_format=pf)
+                assert ok == want_ok and np.array_equal(out, want_c), (fmt.name, w, h, hex(pf))
+                tpx = 1 + ((pf & 0xF00) >> 8)
+                pitch = w * tpx + 7                       # odd pitch: 24-bit pixels are byte-addressed
+                if tpx != 3:
+                    pitch = ((w * tpx + 15) // 16) * 16 + 16
+                canvas = torch.full((h * pitch,), 0xA5, dtype=torch.uint8, device="cuda")
+                binding.decompress_linear_device(fmt, _dev(torch, data), w, h, out=canvas, pitch=pitch, pixel_format=pf)
+                torch.cuda.synchronize()
+                got = canvas.cpu().numpy().reshape(h, pitch)
+                assert np.array_equal(got[:, :w * tpx].reshape(-1), want_c), (fmt.name, w, h, hex(pf), "device pitch")
+                assert (got[:, w * tpx:] == 0xA5).all()
 
 
 # ---- random streams vs the oracle at a size the oracle finishes in well under a second ----------
@@ -165,6 +182,47 @@ def test_random_stream_vs_oracle(fmt, variant, torch_cuda, oracle):
     got_t = binding.decompress_tiled_device(fmt, _dev(torch, data), W // 4, H // 4)
     torch.cuda.synchronize()
     assert np.array_equal(got_t.cpu().numpy(), want_t)
+
+
+@pytest.mark.parametrize("name,pf", [(f.name, pf) for f in F.FORMATS for pf in F.accepted_pixel_formats(f) if F.epilogue_kind(f, pf)])
+def test_epilogue_targets_random_stream(name, pf, torch_cuda, oracle):
+    """in-kernel pixel-format epilogues (BGRA8/BGRX8/RGB8, FLOAT_BGRX16) vs oracle decode + convert"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    W, H = 512, 256
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0xE91 + fmt.index)
+    ok_o, want = oracle.linear_to(fmt, data, W, H, pf)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, pixel_format=pf, status=status)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert bool(status.item() == 0) == ok_o
+    ok_t, want_t = oracle.tiled_to(fmt, data, W // 4, H // 4, pf)
+    got_t = binding.decompress_tiled_device(fmt, _dev(torch, data), W // 4, H // 4, pixel_format=pf)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_t.cpu().numpy(), want_t)
+
+
+def test_full_size_digest_epilogue_targets(torch_cuda, golden_json):
+    from detex_amd import binding
+    torch = torch_cuda
+    dg = golden_json("digests_8192.json")
+    W, H = dg["width"], dg["height"]
+    for key, g in dg["streams"].items():
+        if "/pf" not in key:
+            continue
+        name, _, pfs = key.split("/")
+        fmt, pf = F.BY_NAME[name], int(pfs[2:], 16)
+        data = ol.stream_u(fmt, (W // 4) * (H // 4))
+        assert sha(data) == g["in_sha256"]
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, pixel_format=pf, status=status)
+        torch.cuda.synchronize()
+        assert out.numel() == g["bytes"] and bool(status.item() == 0) == g["ok"]
+        assert sha(out.cpu().numpy()) == g["sha256"], key
+        del out
+        torch.cuda.empty_cache()
 
 
 def test_bc1_tile4x4_variant_matches(torch_cuda, oracle):
@@ -197,7 +255,7 @@ def test_full_size_digest(name, torch_cuda, golden_json):
     W, H = dg["width"], dg["height"]
     kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT") else [])
     for kind in kinds:
-        g = dg["streams"]["%s/%s" % (name, kind)]
+        g = dg["streams"]["%s/%s" % (name, kind)]   # native target; epilogue targets: test_full_size_digest_epilogue_targets
         data = ol.stream_u(fmt, (W // 4) * (H // 4))
         if kind == "M":
             data = streams.stream_m(fmt, data)

@@ -70,6 +70,12 @@ def main():
             ok, o = ref.linear(f, data, w, h)
             clip["%s/%dx%d" % (f.name, w, h)] = o
             clip["%s/%dx%d/ok" % (f.name, w, h)] = np.array([ok])
+            if (w, h) in streams.CLIP_SIZES_CONVERTED:
+                for pf in F.accepted_pixel_formats(f):
+                    if F.epilogue_kind(f, pf):
+                        ok2, o2 = ref.linear(f, data, w, h, pixel_format=pf)
+                        assert ok2 == ok
+                        clip["%s/%dx%d/pf%04X" % (f.name, w, h, pf)] = o2
         print("vectors", f.name, n, "blocks", int(okv.sum()), "valid", flush=True)
     np.savez_compressed(os.path.join(G, "forced_vectors.npz"), **vec)
     np.savez_compressed(os.path.join(G, "clip.npz"), **clip)
@@ -88,6 +94,14 @@ def main():
             dg["streams"]["%s/%s" % (f.name, kind)] = {"ok": ok, "sha256": sha(out), "fnv1a64": "%016x" % fnv,
                 "in_sha256": sha(data), "ref_seconds_1thread": round(dt, 3)}
             print(f.name, kind, ok, "%016x" % fnv, "%.2fs" % dt, flush=True)
+    # converted targets at full size (in-kernel epilogues)
+    for name, pf in (("BC1", F.PIXEL_FORMAT_BGRA8), ("BC1", F.PIXEL_FORMAT_RGB8), ("BC3", F.PIXEL_FORMAT_RGB8),
+                     ("BPTC_FLOAT", F.PIXEL_FORMAT_FLOAT_BGRX16)):
+        f = F.BY_NAME[name]
+        data = ol.stream_u(f, (W // 4) * (H // 4))
+        ok, out = ref.linear(f, data, W, H, pixel_format=pf)
+        dg["streams"]["%s/U/pf%04X" % (name, pf)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
+        print(name, "U pf%04X" % pf, ok, flush=True)
     json.dump(dg, open(os.path.join(G, "digests_8192.json"), "w"), indent=1, sort_keys=True)
 
 if __name__ == "__main__":
