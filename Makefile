@@ -10,10 +10,10 @@ HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include
 all: lib oracle
 lib: $(LIB)
 
-$(LIB): $(CSRC)/detexhip.hip $(HDRS)
+$(LIB): $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp $(HDRS)
 	@mkdir -p detex_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
-		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip
+		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp
 
 oracle:
 	$(MAKE) -C oracle all

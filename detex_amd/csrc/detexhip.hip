@@ -21,6 +21,7 @@
 #include "decode_bptc.h"
 #include "decode_bptc_float.h"
 #include "kernels.h"
+#include "kernels_extra.h"
 #include "variant_tile4x4.h"
 
 using namespace detexhip;
@@ -137,24 +138,67 @@ template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
 	return a.epi == kEpiNone ? launch_blocks_epi<Dec, kEpiNone>(a) : hipErrorInvalidValue;
 }
 
+// 8f-3: all levels of a mip chain in one launch (kernels_extra.h)
+struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; };
+template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
+	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr unsigned align = row_bytes % 16u == 0 ? 16u : (row_bytes % 8u == 0 ? 8u : 4u);
+	for (uint32_t l = 0; l < a.table.n_levels; l++) {
+		LevelDesc &lv = a.table.level[l];
+		const uint32_t hb = lv.width_in_blocks ? lv.n_blocks / lv.width_in_blocks : 0;
+		lv.fast = (lv.width & 3u) == 0 && (lv.height & 3u) == 0 && lv.width_in_blocks * 4u == lv.width && hb * 4u == lv.height &&
+			(reinterpret_cast<uintptr_t>(lv.pixels) % align) == 0 && (lv.pitch % align) == 0;
+	}
+	const uint32_t grid = a.table.wg_start[a.table.n_levels];
+	if (grid == 0) return hipSuccess;
+	hipLaunchKernelGGL((decode_levels<Dec, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status);
+	return hipGetLastError();
+}
+template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
+	if constexpr (target_class<Dec>() == 1) {
+		if (a.epi == kEpiSwapRB8) return launch_levels_epi<Dec, kEpiSwapRB8>(a);
+		if (a.epi == kEpiPackRGB8) return launch_levels_epi<Dec, kEpiPackRGB8>(a);
+	}
+	if constexpr (target_class<Dec>() == 2) {
+		if (a.epi == kEpiSwapRB16) return launch_levels_epi<Dec, kEpiSwapRB16>(a);
+	}
+	return a.epi == kEpiNone ? launch_levels_epi<Dec, kEpiNone>(a) : hipErrorInvalidValue;
+}
+
+// 8f-4: block-mode histogram (kernels_extra.h)
+template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks, size_t n, uint32_t *hist, hipStream_t stream) {
+	hipError_t e = hipMemsetAsync(hist, 0, 16 * sizeof(uint32_t), stream);
+	if (e != hipSuccess || n == 0) return e;
+	const unsigned grid = (unsigned)((n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u);
+	hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS>), dim3(grid), dim3(256), 0, stream, static_cast<const uint32_t *>(blocks),
+		(uint32_t)n, hist);
+	return hipGetLastError();
+}
+
 struct FormatEntry {
 	const char *name;
 	uint32_t texture_format;
 	hipError_t (*linear)(const Geometry &);
 	hipError_t (*blocks)(const BatchArgs &);
+	hipError_t (*levels)(LevelsArgs &);
+	hipError_t (*histogram)(const void *, size_t, uint32_t *, hipStream_t);
 	const char *kernel_name;
 };
 
-#define FMT(NAME, DEC) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, "decode_linear<detexhip::" #DEC }
+#define FMT(NAME, DEC, CLS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_levels<DEC>, \
+	&launch_histogram<CLS, DEC::kBlockBytes / 4>, "decode_linear<detexhip::" #DEC }
 
 const FormatEntry kFormats[20] = {
-	{ nullptr, 0, nullptr, nullptr, nullptr },
-	FMT(BC1, DecBC1), FMT(BC1A, DecBC1A), FMT(BC2, DecBC2), FMT(BC3, DecBC3),
-	FMT(RGTC1, DecRGTC1), FMT(SIGNED_RGTC1, DecSignedRGTC1), FMT(RGTC2, DecRGTC2), FMT(SIGNED_RGTC2, DecSignedRGTC2),
-	FMT(BPTC_FLOAT, DecBPTCFloat), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat), FMT(BPTC, DecBPTC),
-	FMT(ETC1, DecETC1), FMT(ETC2, DecETC2), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough), FMT(ETC2_EAC, DecETC2EAC),
-	FMT(EAC_R11, DecEACR11), FMT(EAC_SIGNED_R11, DecEACSignedR11), FMT(EAC_RG11, DecEACRG11),
-	FMT(EAC_SIGNED_RG11, DecEACSignedRG11),
+	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr },
+	FMT(BC1, DecBC1, kClassS3TC), FMT(BC1A, DecBC1A, kClassS3TC), FMT(BC2, DecBC2, kClassS3TCat8), FMT(BC3, DecBC3, kClassS3TCat8),
+	FMT(RGTC1, DecRGTC1, kClassNone), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone), FMT(RGTC2, DecRGTC2, kClassNone),
+	FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone),
+	FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat),
+	FMT(BPTC, DecBPTC, kClassBPTC),
+	FMT(ETC1, DecETC1, kClassETC1), FMT(ETC2, DecETC2, kClassETC2), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough, kClassETC2PT),
+	FMT(ETC2_EAC, DecETC2EAC, kClassETC2at8),
+	FMT(EAC_R11, DecEACR11, kClassNone), FMT(EAC_SIGNED_R11, DecEACSignedR11, kClassNone), FMT(EAC_RG11, DecEACRG11, kClassNone),
+	FMT(EAC_SIGNED_RG11, DecEACSignedRG11, kClassNone),
 };
 
 const FormatEntry *lookup_format(uint32_t texture_format) {
@@ -303,6 +347,52 @@ extern "C" const char *detexhipKernelName(uint32_t texture_format) {
 	return f->kernel_name;
 }
 
+// 8f-3 device tier: up to 16 levels, one launch
+extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, const detexhipLevel *levels, int n_levels,
+		uint32_t pixel_format, void *stream, uint32_t *d_status) {
+	const char *who = "detexhipDecompressLevelsLinearDevice";
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
+	const int epi = epilogue_for(texture_format, pixel_format);
+	if (epi < 0) { detexSetErrorMessage("%s: pixel format 0x%08X is outside the block-decode path for format 0x%08X", who, pixel_format, texture_format); return 1; }
+	if (n_levels < 0 || n_levels > kMaxLevels || (n_levels > 0 && !levels)) { detexSetErrorMessage("%s: 0..%d levels per call", who, kMaxLevels); return 1; }
+	const size_t px = (size_t)detexGetPixelSize(pixel_format), palign = px == 3 ? 1 : (px < 4 ? px : 4);
+	LevelsArgs a{};
+	a.status = d_status; a.stream = static_cast<hipStream_t>(stream); a.epi = epi;
+	a.table.n_levels = (uint32_t)n_levels;
+	uint32_t wg = 0;
+	for (int l = 0; l < n_levels; l++) {
+		const detexhipLevel &s = levels[l];
+		if (s.width < 0 || s.height < 0 || s.width_in_blocks < 0 || s.height_in_blocks < 0 || s.pitch_bytes < (size_t)s.width * px ||
+				(s.pitch_bytes % palign) != 0 || (reinterpret_cast<uintptr_t>(s.d_pixels) % palign) != 0 ||
+				(uint64_t)s.width_in_blocks * (uint64_t)s.height_in_blocks > 0x7FFFFF00ull) {
+			detexSetErrorMessage("%s: bad geometry in level %d", who, l);
+			return 1;
+		}
+		LevelDesc &d = a.table.level[l];
+		d.blocks = s.d_blocks; d.pixels = static_cast<uint8_t *>(s.d_pixels); d.pitch = s.pitch_bytes;
+		d.width_in_blocks = (uint32_t)s.width_in_blocks; d.n_blocks = (uint32_t)(s.width_in_blocks * s.height_in_blocks);
+		d.width = (uint32_t)s.width; d.height = (uint32_t)s.height;
+		a.table.wg_start[l] = wg;
+		wg += (d.n_blocks + 255u) / 256u;
+	}
+	a.table.wg_start[n_levels] = wg;
+	hipError_t e = f->levels(a);
+	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+	return 0;
+}
+
+// 8f-4 device tier
+extern "C" int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist,
+		void *stream) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("detexhipModeHistogramDevice: 0x%08X is not a block-compressed format of this library", texture_format); return 1; }
+	if (n_blocks > 0xFFFFFF00ull || !d_hist) { detexSetErrorMessage("detexhipModeHistogramDevice: bad arguments"); return 1; }
+	hipError_t e = f->histogram(d_blocks, n_blocks, d_hist, static_cast<hipStream_t>(stream));
+	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+	return 0;
+}
+
 extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, const void *d_blocks, int width,
 		int height, int width_in_blocks, int height_in_blocks, void *d_pixels, size_t pitch_bytes,
 		uint32_t pixel_format, void *stream, uint32_t *d_status) {
@@ -439,6 +529,72 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
 		return false;
 	}
+	return true;
+}
+
+// 8f-3 host tier: what a caller of detexLoadKTXFileWithMipmaps does level by level (one
+// detexDecompressTextureLinear per level), as one staging copy in, ONE launch, one copy out.
+extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *textures, int n_textures,
+		uint8_t *const *pixel_buffers, uint32_t pixel_format) {
+	const char *who = "detexhipDecompressTexturesLinear";
+	if (n_textures <= 0) return true;
+	if (n_textures > kMaxLevels) { detexSetErrorMessage("%s: at most %d textures per call", who, kMaxLevels); return false; }
+	const uint32_t format = textures[0]->format;
+	const FormatEntry *f = lookup_format(format);
+	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	if (!f || !pixel_format_accepted(format, pixel_format)) {
+		for (int l = 0; l < n_textures; l++) memset(pixel_buffers[l], 0, (size_t)textures[l]->width * (size_t)textures[l]->height * px);
+		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who, format, pixel_format);
+		return false;
+	}
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	const size_t bs = detexGetCompressedBlockSize(format);
+	size_t in_off[kMaxLevels], out_off[kMaxLevels], in_total = 0, out_total = 0;
+	for (int l = 0; l < n_textures; l++) {
+		if (textures[l]->format != format) { detexSetErrorMessage("%s: all textures must share one format", who); return false; }
+		in_off[l] = in_total; out_off[l] = out_total;
+		in_total += ((size_t)textures[l]->width_in_blocks * (size_t)textures[l]->height_in_blocks * bs + 255) & ~(size_t)255;
+		out_total += ((size_t)textures[l]->width * (size_t)textures[l]->height * px + 255) & ~(size_t)255;
+	}
+	if (!reserve(&c.d_in, &c.in_cap, in_total ? in_total : 256) || !reserve(&c.d_out, &c.out_cap, out_total ? out_total : 256)) return false;
+	detexhipLevel lv[kMaxLevels];
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	for (int l = 0; l < n_textures; l++) {
+		const detexTexture *t = textures[l];
+		const size_t nbytes = (size_t)t->width_in_blocks * (size_t)t->height_in_blocks * bs;
+		if (nbytes) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(c.d_in) + in_off[l], t->data, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+		lv[l] = detexhipLevel{ static_cast<uint8_t *>(c.d_in) + in_off[l], static_cast<uint8_t *>(c.d_out) + out_off[l],
+			(size_t)t->width * px, t->width, t->height, t->width_in_blocks, t->height_in_blocks };
+	}
+	if (detexhipDecompressLevelsLinearDevice(format, lv, n_textures, pixel_format, c.stream, c.d_status) != 0) return false;
+	uint32_t status = 0;
+	for (int l = 0; l < n_textures; l++) {
+		const size_t nbytes = (size_t)textures[l]->width * (size_t)textures[l]->height * px;
+		if (nbytes) HIP_TRY(hipMemcpyAsync(pixel_buffers[l], static_cast<uint8_t *>(c.d_out) + out_off[l], nbytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	}
+	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	if (status != 0) {
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", format);
+		return false;
+	}
+	return true;
+}
+
+// 8f-4 host tier: histogram[m] = number of blocks whose detexGetMode<FMT> is m (bin 15: reserved codes)
+extern "C" bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks, uint32_t histogram[16]) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("detexhipModeHistogram: 0x%08X is not a block-compressed format of this library", texture_format); return false; }
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	const size_t nbytes = n_blocks * detexGetCompressedBlockSize(texture_format);
+	if (!reserve(&c.d_in, &c.in_cap, nbytes ? nbytes : 256)) return false;
+	if (nbytes) HIP_TRY(hipMemcpyAsync(c.d_in, blocks, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	uint32_t *d_hist = c.d_status;		// 16 words (the status allocation is 64 bytes)
+	if (detexhipModeHistogramDevice(texture_format, c.d_in, n_blocks, d_hist, c.stream) != 0) return false;
+	HIP_TRY(hipMemcpyAsync(histogram, d_hist, 64, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 	return true;
 }
 

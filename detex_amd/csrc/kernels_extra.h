@@ -1,0 +1,111 @@
+// kernels_extra.h -- the "next" rows of SURVEY.md section 8(f) that sit directly on the hot path:
+//   8f-3  mip-chain batching: every level of a chain (ktx.c:108-171 yields them as separate small
+//         textures) decoded by ONE launch over a descriptor table, so the small levels do not each
+//         pay a launch + a mostly empty grid;
+//   8f-4  block-mode histograms (the reference's detexGetMode<FMT> helpers, decompress-bc.c:63-69,
+//         decompress-etc.c:183-190,370-395,721-742, decompress-bptc.c:603-610,
+//         decompress-bptc-float.c:647-658) computed on the GPU over a whole block stream.
+#pragma once
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace detexhip {
+
+// ---- 8f-3: one launch over up to 16 levels ------------------------------------------------------
+constexpr int kMaxLevels = 16;
+struct LevelDesc {
+	const void *blocks; uint8_t *pixels; uint64_t pitch;
+	uint32_t width_in_blocks, n_blocks, width, height;
+	uint32_t fast;			// 4-aligned geometry + vector-aligned rows: wave-wide row stores
+	uint32_t pad;
+};
+struct LevelTable {
+	uint32_t n_levels;
+	uint32_t wg_start[kMaxLevels + 1];	// first workgroup of each level; [n_levels] = grid size
+	LevelDesc level[kMaxLevels];
+};
+
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status) {
+	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	// workgroup -> level: wave-uniform scalar search over <= 16 entries
+	uint32_t l = 0;
+	for (uint32_t k = 1; k < table.n_levels; k++) l = blockIdx.x >= table.wg_start[k] ? k : l;
+	const LevelDesc &lv = table.level[l];
+	const uint32_t i = (blockIdx.x - table.wg_start[l]) * 256u + threadIdx.x;
+	if (i >= lv.n_blocks) return;
+	uint32_t o[4 * ROW];
+	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
+	const uint32_t by = i / lv.width_in_blocks, bx = i - by * lv.width_in_blocks;
+	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
+	if (lv.fast) {
+#pragma unroll
+		for (int r = 0; r < 4; r++) store_row<ROW, true>(dst + (uint64_t)r * lv.pitch, o + r * ROW);
+	} else {
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			if (by * 4u + r >= lv.height) continue;
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				if (bx * 4u + x < lv.width) store_pixel<ROW>(dst + (uint64_t)r * lv.pitch + x * ROW, o + r * ROW, x);
+		}
+	}
+	raise_status(!ok, status);
+}
+
+// ---- 8f-4: mode classification ------------------------------------------------------------------
+// Bin numbers are the reference's detexGetMode<FMT> return values; bin 15 collects the reserved
+// BPTC / BPTC_FLOAT codes (where the reference returns -1).  Formats without modes use bin 0.
+enum : int { kClassS3TC = 0, kClassS3TCat8, kClassETC1, kClassETC2, kClassETC2PT, kClassETC2at8, kClassBPTC, kClassBPTCFloat, kClassNone };
+
+DH uint32_t etc2_mode_of(uint32_t w0, bool has_individual) {	// decompress-etc.c:370-395
+	const uint32_t b0 = w0 & 0xFFu, b1 = (w0 >> 8) & 0xFFu, b2 = (w0 >> 16) & 0xFFu, b3 = w0 >> 24;
+	if (has_individual && !(b3 & 2u)) return 0u;
+	const bool ovr = (uint32_t)((int32_t)(b0 >> 3) + sbfe(b0, 0, 3)) > 31u;
+	const bool ovg = (uint32_t)((int32_t)(b1 >> 3) + sbfe(b1, 0, 3)) > 31u;
+	const bool ovb = (uint32_t)((int32_t)(b2 >> 3) + sbfe(b2, 0, 3)) > 31u;
+	return ovr ? 2u : (ovg ? 3u : (ovb ? 4u : 1u));
+}
+
+template <int CLASS> DH uint32_t block_mode(const uint32_t *w) {	// w = the block's 2 or 4 dwords
+	if constexpr (CLASS == kClassS3TC) return (w[0] & 0xFFFFu) > (w[0] >> 16) ? 0u : 1u;
+	else if constexpr (CLASS == kClassS3TCat8) return (w[2] & 0xFFFFu) > (w[2] >> 16) ? 0u : 1u;
+	else if constexpr (CLASS == kClassETC1) return (w[0] >> 25) & 1u;
+	else if constexpr (CLASS == kClassETC2) return etc2_mode_of(w[0], true);
+	else if constexpr (CLASS == kClassETC2PT) return etc2_mode_of(w[0], false);
+	else if constexpr (CLASS == kClassETC2at8) return etc2_mode_of(w[2], true);
+	else if constexpr (CLASS == kClassBPTC) return (w[0] & 0xFFu) ? (uint32_t)__builtin_ctz(w[0] & 0xFFu) : 15u;
+	else if constexpr (CLASS == kClassBPTCFloat) {
+		const uint32_t low2 = w[0] & 3u, low5 = w[0] & 0x1Fu;
+		const uint32_t m = low2 < 2u ? low2 : (low2 == 2u ? 2u + (low5 >> 2) : 10u + (low5 >> 2));
+		return m > 13u ? 15u : m;
+	} else return 0u;
+}
+
+// Persistent grid-stride kernel: per-wave ballots -> LDS counters -> 16 atomics per workgroup.
+template <int CLASS, int BLOCK_DWORDS>
+__global__ __launch_bounds__(256) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
+		uint32_t *__restrict__ hist) {
+	__shared__ uint32_t bins[16];
+	if (threadIdx.x < 16) bins[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t local[16];
+#pragma unroll
+	for (int m = 0; m < 16; m++) local[m] = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_blocks; i += gridDim.x * 256u) {
+		uint32_t w[BLOCK_DWORDS];
+		if constexpr (BLOCK_DWORDS == 2) { const uint2 v = reinterpret_cast<const uint2 *>(blocks)[i]; w[0] = v.x; w[1] = v.y; }
+		else { const uint4 v = reinterpret_cast<const uint4 *>(blocks)[i]; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+		const uint32_t mode = block_mode<CLASS>(w);
+#pragma unroll
+		for (int m = 0; m < 16; m++) local[m] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mode == (uint32_t)m));
+	}
+	if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+		for (int m = 0; m < 16; m++) if (local[m]) atomicAdd(&bins[m], local[m]);
+	}
+	__syncthreads();
+	if (threadIdx.x < 16 && bins[threadIdx.x]) atomicAdd(&hist[threadIdx.x], bins[threadIdx.x]);
+}
+
+}  // namespace detexhip

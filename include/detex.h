@@ -152,6 +152,15 @@ DETEX_API bool detexDecompressTextureTiled(const detexTexture *texture, uint8_t 
 DETEX_API bool detexDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer,
 	uint32_t pixel_format);						/* texture.c:105 */
 
+/* ---- KTX1 loader for block-compressed payloads (detex.h:826-836, ktx.c:36-189) -----------
+ * enough of the reference's loader that its own call sequence
+ * (detexLoadKTXFile -> detexDecompressTextureLinear, validate.c:135,208) runs against this
+ * library.  Textures and their data are malloc'ed; the caller frees them (as in the reference).
+ * Uncompressed payloads and the other containers (DDS/raw/PNG) are not provided. */
+DETEX_API bool detexLoadKTXFileWithMipmaps(const char *filename, int max_mipmaps, detexTexture ***textures_out,
+	int *nu_levels_out);							/* ktx.c:36 */
+DETEX_API bool detexLoadKTXFile(const char *filename, detexTexture **texture_out);	/* ktx.c:180 */
+
 /* ---- error convention (detex.h:806, misc.c:73-94): thread-local last-error string,
  * NULL until the first error on the calling thread, overwritten by each later error. */
 DETEX_API const char *detexGetErrorMessage(void);

@@ -18,6 +18,7 @@
 #define DETEXHIP_H
 
 #include <stddef.h>
+#include <stdbool.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -64,6 +65,40 @@ DETEXHIP_API int detexhipDecompressTextureTiledDevice(uint32_t texture_format, c
  * (uint8_t, optional) receives the leaf function's bool; failed blocks are zero-filled. */
 DETEXHIP_API int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
 	uint32_t mode_mask, uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream);
+
+/* ---- mip-chain batching -------------------------------------------------------
+ * Every level of a mip chain (what detexLoadKTXFileWithMipmaps returns as separate textures,
+ * ktx.c:108-171) decoded by ONE kernel launch over a descriptor table; levels follow the same
+ * rules as detexhipDecompressTextureLinearDevice (clipping, fast/clipped store path per level).
+ * At most 16 levels per call (a full chain of a 32768^2 texture). */
+typedef struct {
+	const void *d_blocks;		/* width_in_blocks * height_in_blocks blocks, row-major */
+	void *d_pixels;
+	size_t pitch_bytes;
+	int width, height, width_in_blocks, height_in_blocks;
+} detexhipLevel;
+DETEXHIP_API int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, const detexhipLevel *levels,
+	int n_levels, uint32_t pixel_format, void *stream, uint32_t *d_status);
+
+/* Host-pointer form: n textures of one format (e.g. the array from detexLoadKTXFileWithMipmaps),
+ * each decoded into pixel_buffers[i] exactly as detexDecompressTextureLinear would -- one staging
+ * copy in, one launch, one copy out.  Returns false if any block of any level was invalid. */
+#if !defined(__DETEX_H__) && !defined(DETEXHIP_COMPAT_DETEX_H)
+#include "detex.h"
+#endif
+DETEXHIP_API bool detexhipDecompressTexturesLinear(const detexTexture *const *textures, int n_textures,
+	uint8_t *const *pixel_buffers, uint32_t pixel_format);
+
+/* ---- block-mode histogram -----------------------------------------------------
+ * histogram[m] = number of blocks for which the reference's detexGetMode<FMT> returns m
+ * (decompress-bc.c:63-69, decompress-etc.c:183-190,370-395,721-742, decompress-bptc.c:603-610,
+ * decompress-bptc-float.c:647-658); bin 15 collects the reserved BPTC / BPTC_FLOAT codes (the
+ * reference returns -1 there); formats without modes (RGTC, EAC R11/RG11) count into bin 0.
+ * d_hist: 16 uint32_t, zeroed by the call. */
+DETEXHIP_API int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
+	uint32_t *d_hist, void *stream);
+DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,
+	uint32_t histogram[16]);
 
 /* Kernel-variant selection for A/B measurements (bench.py --variant):
  *   0  lane-per-block, 64x1-block wave tiles, non-temporal row stores (default)
