@@ -98,6 +98,103 @@ template <int M> DH Bc6hParams bc6h_mode(Bits128 b, uint32_t (&ep)[3][4]) {
 	return Bc6hParams{ (uint32_t)kBc6hEpb[M], (uint32_t)kBc6hDelta[M][0], (uint32_t)kBc6hDelta[M][1], (uint32_t)kBc6hDelta[M][2] };
 }
 
+// ---- divergence-free scatter ------------------------------------------------------------------------
+// The 14-way switch above costs ~55 VALU ops per mode PRESENT in the wave (all 14 on mixed content).
+// Every layout, however, keeps its main fields at fixed positions -- r0@5 g0@15 b0@25 r1@35 g1@45 b1@55
+// r2@65 r3@71 and g2[3:0]@41 g3[3:0]@51 b2[3:0]@61 -- and differs only in (a) the field widths and
+// (b) where 15 "loose" bits (g2[4:5] g3[4:5] b2[4:5] b3[0:5] r0/g0/b0[10]) sit among 25 candidate
+// positions; the one-subset modes store the high bits of r0/g0/b0 bit-reversed right after r1/g1/b1.
+// So one straight-line path serves all modes: widths and loose-bit routes come from a 4-dword
+// descriptor per mode in __constant__ memory, DERIVED AT COMPILE TIME from the spec strings above.
+constexpr int kLooseSrc[25] = { 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 39, 40, 49, 50, 59, 60, 69, 70, 75, 76 };
+struct Bc6hModeWords { uint32_t a, b, c, d; };	// a: w0 | rw<<4 | gw<<8 | bw<<12 | epb<<16 | transformed<<21; b,c,d: 15 x 5-bit routes
+constexpr int bc6h_loose_slot(int comp, int ep, int bit) {
+	if (comp == 1 && ep == 2 && (bit == 4 || bit == 5)) return bit - 4;		// g2[4], g2[5]
+	if (comp == 1 && ep == 3 && (bit == 4 || bit == 5)) return 2 + bit - 4;		// g3[4], g3[5]
+	if (comp == 2 && ep == 2 && (bit == 4 || bit == 5)) return 4 + bit - 4;		// b2[4], b2[5]
+	if (comp == 2 && ep == 3 && bit < 6) return 6 + bit;				// b3[0..5]
+	if (ep == 0 && bit == 10) return 12 + comp;					// r0[10], g0[10], b0[10]
+	return -1;
+}
+struct Bc6hDerived { Bc6hModeWords w; bool ok; };
+constexpr Bc6hDerived bc6h_derive(int M) {
+	const Bc6hLayout L = bc6h_parse(kBc6hLayout[M], M < 2 ? 2 : 5);
+	constexpr int main_pos[3][4] = { { 5, 35, 65, 71 }, { 15, 45, 41, 51 }, { 25, 55, 61, -1 } };
+	uint32_t w0 = 0, w1[3] = { 0, 0, 0 }, route[15] = { 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31 };
+	bool ok = true;
+	for (int s = 0; s < L.n; s++) {
+		const Bc6hSeg g = L.seg[s];
+		if (g.dst_lo == 0 && g.len > 1) {			// a main field: must sit at its canonical position
+			ok = ok && g.pos == main_pos[g.comp][g.ep] && !g.rev;
+			if (g.ep == 0) { ok = ok && (w0 == 0 || w0 == (uint32_t)g.len); w0 = (uint32_t)g.len; }
+			else if (g.ep == 1) w1[g.comp] = (uint32_t)g.len;
+			else if (g.comp == 0) ok = ok && (uint32_t)g.len == w1[0];	// r2, r3 are as wide as r1
+			else ok = ok && g.len == 4;					// g2/g3/b2 low nibbles
+		} else if (M >= 10) {					// reversed high bits of r0/g0/b0 directly after r1/g1/b1
+			ok = ok && g.ep == 0 && g.dst_lo == 10 && g.pos == main_pos[g.comp][1] + (int)w1[g.comp] && g.len == 10 - (int)w1[g.comp] &&
+				(g.rev || g.len == 1);
+		} else {						// a loose bit
+			const int slot = bc6h_loose_slot(g.comp, g.ep, g.dst_lo);
+			int idx = -1;
+			for (int k = 0; k < 25; k++) if (kLooseSrc[k] == g.pos) idx = k;
+			ok = ok && g.len == 1 && slot >= 0 && idx >= 0;
+			if (slot >= 0 && idx >= 0) route[slot] = (uint32_t)idx;
+		}
+	}
+	const bool transformed = kBc6hDelta[M][0] != 0;
+	if (transformed) ok = ok && (uint32_t)kBc6hDelta[M][0] == w1[0] && (uint32_t)kBc6hDelta[M][1] == w1[1] && (uint32_t)kBc6hDelta[M][2] == w1[2];
+	Bc6hModeWords w{};
+	w.a = w0 | (w1[0] << 4) | (w1[1] << 8) | (w1[2] << 12) | ((uint32_t)kBc6hEpb[M] << 16) | ((transformed ? 1u : 0u) << 21);
+	for (int k = 0; k < 6; k++) { w.b |= route[k] << (5 * k); w.c |= route[6 + k] << (5 * k); }
+	for (int k = 0; k < 3; k++) w.d |= route[12 + k] << (5 * k);
+	return Bc6hDerived{ w, ok };
+}
+#define BC6H_CHECK(M) static_assert(bc6h_derive(M).ok, "BC6H layout does not fit the canonical-position scheme")
+BC6H_CHECK(0); BC6H_CHECK(1); BC6H_CHECK(2); BC6H_CHECK(3); BC6H_CHECK(4); BC6H_CHECK(5); BC6H_CHECK(6);
+BC6H_CHECK(7); BC6H_CHECK(8); BC6H_CHECK(9); BC6H_CHECK(10); BC6H_CHECK(11); BC6H_CHECK(12); BC6H_CHECK(13);
+#undef BC6H_CHECK
+__constant__ Bc6hModeWords kBc6hModeWords[14] = {
+	bc6h_derive(0).w, bc6h_derive(1).w, bc6h_derive(2).w, bc6h_derive(3).w, bc6h_derive(4).w, bc6h_derive(5).w, bc6h_derive(6).w,
+	bc6h_derive(7).w, bc6h_derive(8).w, bc6h_derive(9).w, bc6h_derive(10).w, bc6h_derive(11).w, bc6h_derive(12).w, bc6h_derive(13).w,
+};
+
+DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t (&ep)[3][4]) {
+	const Bc6hModeWords mw = kBc6hModeWords[mode];
+	const uint32_t w0 = mw.a & 15u, rw = ubfe(mw.a, 4, 4), gw = ubfe(mw.a, 8, 4), bw = ubfe(mw.a, 12, 4);
+	const bool transformed = (mw.a >> 21) & 1u, one = mode >= 10u;
+	// main fields at their canonical positions, per-lane widths
+	const uint32_t win35 = field_at<35, 32>(b), win45 = field_at<45, 32>(b);
+	uint32_t win55 = field_at<55, 32>(b);
+	win55 = mode == 12u ? (win55 & ~0x100u) : win55;	// QUIRK A-3: block bit 63 (b0[11] of mode 12) reads 0
+	ep[0][0] = ubfe(field_at<5, 10>(b), 0, w0);
+	ep[1][0] = ubfe(field_at<15, 10>(b), 0, w0);
+	ep[2][0] = ubfe(field_at<25, 10>(b), 0, w0);
+	ep[0][1] = ubfe(win35, 0, rw);
+	ep[1][1] = ubfe(win45, 0, gw);
+	ep[2][1] = ubfe(win55, 0, bw);
+	ep[0][2] = ubfe(field_at<65, 6>(b), 0, rw);
+	ep[0][3] = ubfe(field_at<71, 6>(b), 0, rw);
+	// the 25 candidate positions of the loose bits, compacted into one word (bit 31 stays 0 = "no source")
+	const uint32_t pool = field_at<2, 3>(b) | (field_at<11, 4>(b) << 3) | (field_at<21, 4>(b) << 7) | (field_at<31, 4>(b) << 11) |
+		(field_at<39, 2>(b) << 15) | (field_at<49, 2>(b) << 17) | (field_at<59, 2>(b) << 19) | (field_at<69, 2>(b) << 21) |
+		(field_at<75, 2>(b) << 23);
+	uint32_t bit[15];
+#pragma unroll
+	for (int k = 0; k < 15; k++) bit[k] = ubfe(pool, ubfe(k < 6 ? mw.b : (k < 12 ? mw.c : mw.d), 5 * (k % 6), 5), 1);
+	ep[1][2] = field_at<41, 4>(b) | (bit[0] << 4) | (bit[1] << 5);
+	ep[1][3] = field_at<51, 4>(b) | (bit[2] << 4) | (bit[3] << 5);
+	ep[2][2] = field_at<61, 4>(b) | (bit[4] << 4) | (bit[5] << 5);
+	ep[2][3] = bit[6] | (bit[7] << 1) | (bit[8] << 2) | (bit[9] << 3) | (bit[10] << 4) | (bit[11] << 5);
+	// one-subset modes: r0/g0/b0[10..] follow r1/g1/b1 bit-reversed (decompress-bptc-float.c:441-485)
+	const uint32_t hr = __brev(ubfe(win35, rw, 10u - rw)) >> ((22u + rw) & 31u);
+	const uint32_t hg = __brev(ubfe(win45, gw, 10u - gw)) >> ((22u + gw) & 31u);
+	const uint32_t hb = __brev(ubfe(win55, bw, 10u - bw)) >> ((22u + bw) & 31u);
+	ep[0][0] |= (one ? hr : bit[12]) << 10;
+	ep[1][0] |= (one ? hg : bit[13]) << 10;
+	ep[2][0] |= (one ? hb : bit[14]) << 10;
+	return Bc6hParams{ ubfe(mw.a, 16, 5), transformed ? rw : 0u, transformed ? gw : 0u, transformed ? bw : 0u };
+}
+
 // decompress-bptc-float.c:52-63
 DH int32_t bc6h_unquantize_unsigned(uint32_t x, uint32_t epb) {
 	const uint32_t mid = ((x << 15) + 0x4000u) >> ((epb - 1u) & 31u);
@@ -114,7 +211,9 @@ DH int32_t bc6h_unquantize_signed(int32_t x, uint32_t epb) {
 	return epb >= 16u ? x : s;
 }
 
-template <bool SIGNED> struct DecBPTCFloatT {
+// SWITCH_SCATTER = true keeps the per-mode switch (cheaper when a whole wave shares one mode); the
+// default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
+template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8;
 
 	// decompress-bptc-float.c:110-626
@@ -127,7 +226,8 @@ template <bool SIGNED> struct DecBPTCFloatT {
 		if (CHECKED && !(mode_mask & (1u << mode))) return false;
 		uint32_t ep[3][4] = {};
 		Bc6hParams p;
-		switch (mode) {
+		if (!SWITCH_SCATTER) p = bc6h_scatter_generic(b, mode, ep);
+		else switch (mode) {
 		case 0: p = bc6h_mode<0>(b, ep); break;
 		case 1: p = bc6h_mode<1>(b, ep); break;
 		case 2: p = bc6h_mode<2>(b, ep); break;
@@ -170,6 +270,16 @@ template <bool SIGNED> struct DecBPTCFloatT {
 		uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
 		uint32_t hi = two ? (blk.w >> 18) : (blk.w >> 1);
 		const WeightParams wp = weight_params(ibits);
+		// ((64-w)*e0 + w*e1 + 32) >> 6  ==  (64*e0 + 32 + w*(e1-e0)) >> 6  (:97-108): per subset keep
+		// base = 64*e0 + 32 and diff = e1 - e0, so a texel channel is one v_mad_i32_i24 + one shift
+		int32_t base[3][2], diff[3][2];
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+#pragma unroll
+			for (int s = 0; s < 2; s++) {
+				base[c][s] = q[c][2 * s] * 64 + 32;
+				diff[c][s] = q[c][2 * s + 1] - q[c][2 * s];
+			}
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			const uint32_t width = ibits - ((amask >> i) & 1u);	// anchor texels store one bit less
@@ -180,19 +290,20 @@ template <bool SIGNED> struct DecBPTCFloatT {
 			uint32_t h[3];
 #pragma unroll
 			for (int c = 0; c < 3; c++) {
-				const int32_t e0 = (int32_t)bfi(ms, (uint32_t)q[c][2], (uint32_t)q[c][0]);
-				const int32_t e1 = (int32_t)bfi(ms, (uint32_t)q[c][3], (uint32_t)q[c][1]);
-				const int32_t v = (__mul24(64 - w, e0) + __mul24(w, e1) + 32) >> 6;	// :97-108
-				if (SIGNED) {				// :576-609 sign-magnitude half
-					const bool neg = v < 0;
-					const uint32_t m = (uint32_t)__mul24(neg ? -v : v, 31) >> 5;
-					h[c] = m | ((neg && m != 0u) ? 0x8000u : 0u);
+				const int32_t bs = (int32_t)bfi(ms, (uint32_t)base[c][1], (uint32_t)base[c][0]);
+				const int32_t df = (int32_t)bfi(ms, (uint32_t)diff[c][1], (uint32_t)diff[c][0]);
+				const int32_t v = (bs + __mul24(w, df)) >> 6;
+				if (SIGNED) {				// :576-609 sign-magnitude half: m = (|v|*31)>>5, sign only if m != 0
+					const uint32_t m = (uint32_t)__mul24(max(v, -v), 31) >> 5;
+					const uint32_t hs = m | (((uint32_t)v >> 16) & 0x8000u);
+					h[c] = m ? hs : 0u;
 				} else {
 					h[c] = (uint32_t)__mul24(v, 31) >> 6;	// :613-621 (v >= 0: /64 == >>6)
 				}
 			}
-			d[2 * i] = (h[0] & 0xFFFFu) | (h[1] << 16);
-			d[2 * i + 1] = h[2] & 0xFFFFu;			// X = 0
+			d[2 * i] = perm(h[1], h[0], 0x05040100u);	// every h < 2^16; v_perm keeps the compiler from fusing
+									// the shift into a (40x slower) v_mul_lo_u32
+			d[2 * i + 1] = h[2];				// X = 0
 		}
 		return true;
 	}

@@ -47,14 +47,30 @@ DETEX_HD uint32_t bptc_weight(uint32_t index, uint32_t bits) {
 #else
 #define DETEX_UMUL24(a, b) (((a) & 0xFFFFFFu) * ((b) & 0xFFFFFFu))
 #endif
-DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) { return (((uint32_t)(v + 127) * 65535u) / 254u - 32768u) & 0xFFFFu; }
+// division-free: 65535 = 254*258 + 3, so n*65535/254 = n*258 + floor(3n/254) with floor(3n/254) = (n>=85)+(n>=170)+(n>=254)
+DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) {
+	const uint32_t n = (uint32_t)(v + 127);
+	return (n * 258u + (n >= 85u ? 1u : 0u) + (n >= 170u ? 1u : 0u) + (n >= 254u ? 1u : 0u) - 32768u) & 0xFFFFu;
+}
 
 #if defined(DETEXHIP_DEVICE_CODE)
 // ---- single-instruction bit-field idioms ---------------------------------------------------
 DH uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 DH int32_t sbfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_sbfe((int32_t)v, off, width); }
+// Lane masks are made OPAQUE to the optimiser.  Left visible, hipcc proves a mask is 0 / ~0 and
+// rewrites every (a & m) | (b & ~m) into v_cmp + v_cndmask_b32; runs of VOP2-encoded
+// v_cndmask_b32 issue at ~23 cycles each on MI355X (tools/ubench/valu_rates.hip: 23.3 vs 4.5 for
+// v_bfi_b32 and 4.4 for the VOP3 encoding) -- it made the *shorter* unsigned BC6H kernel 1.5x slower
+// than the signed one.  The empty asm costs no instruction; selects then stay v_bfi_b32.
+#if defined(__HIPCC__)
+DH uint32_t opaque(uint32_t m) { asm("" : "+v"(m)); return m; }
+#else
+DH uint32_t opaque(uint32_t m) { return m; }
+#endif
 // all-ones if bit `bit` of v is set, else 0 (v_bfe_i32 of a 1-bit field)
-DH uint32_t bit_to_mask(uint32_t v, uint32_t bit) { return (uint32_t)__builtin_amdgcn_sbfe((int32_t)v, bit, 1u); }
+DH uint32_t bit_to_mask(uint32_t v, uint32_t bit) { return opaque((uint32_t)__builtin_amdgcn_sbfe((int32_t)v, bit, 1u)); }
+// all-ones if c, else 0: one v_cndmask to build the mask, then any number of v_bfi_b32 selects
+DH uint32_t cond_to_mask(bool c) { return opaque(c ? 0xFFFFFFFFu : 0u); }
 // (a & m) | (b & ~m)  -> v_bfi_b32
 DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 // byte permute: result byte i = byte sel[i] of the 8-byte pool {s0 (4..7), s1 (0..3)}; 0x0C -> 0x00

@@ -102,6 +102,20 @@ DH void raise_status(bool bad, uint32_t *status) {
 		__hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// block index -> (block row, block column).  Texture widths are almost always powers of two, where
+// this is a shift and a mask on a wave-uniform (kernel-argument) width.  The generic 32-bit division
+// compiles to v_mul_hi_u32 / v_mul_lo_u32, which were measured ~40x slower than ordinary VALU ops
+// on MI355X, so it is kept off the common path.
+DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t &bx) {
+	if ((width_in_blocks & (width_in_blocks - 1u)) == 0u) {
+		by = i >> __builtin_ctz(width_in_blocks);
+		bx = i & (width_in_blocks - 1u);
+	} else {
+		by = i / width_in_blocks;
+		bx = i - by * width_in_blocks;
+	}
+}
+
 // decode + zero-fill on failure + epilogue; returns ok
 template <class Dec, int EPI, bool CHECKED>
 DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
@@ -129,8 +143,41 @@ __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ bl
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
 	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
-	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
+	uint32_t by, bx;
+	split_index(i, width_in_blocks, by, bx);
 	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
+	if constexpr (ROW == 8 && NT) {
+		// 64-bit pixels: a lane's row is 32 B, so a plain dwordx4 store writes 16 of every 32 bytes
+		// and the line is completed by the NEXT instruction -- measured 2.5 TB/s for streaming stores
+		// (BC6H 217 us).  Transpose each row through 2 KiB of LDS per wave so that every store
+		// instruction covers one contiguous 1 KiB run, as for the 32-bit formats.  Needs the wave's 64
+		// blocks in one block row (width_in_blocks % 64 == 0; then every wave is also full).
+		if ((width_in_blocks & 63u) == 0u) {
+			typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+			__shared__ v4 xpose[4][128];
+			v4 *slab = xpose[threadIdx.x >> 6];
+			const uint32_t lane = threadIdx.x & 63u;
+			uint8_t *row0 = dst - (uint64_t)lane * 32u;		// start of the wave's 2 KiB row segment
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				slab[2 * lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
+				slab[2 * lane + 1] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+				// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
+				// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const v4 a = slab[lane], b = slab[64 + lane];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				v4 *out = reinterpret_cast<v4 *>(row0 + (uint64_t)r * pitch);
+				__builtin_nontemporal_store(a, out + lane);
+				__builtin_nontemporal_store(b, out + 64 + lane);
+			}
+			raise_status(!ok, status);
+			return;
+		}
+	}
 #pragma unroll
 	for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
 	raise_status(!ok, status);
@@ -158,7 +205,8 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
 	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
-	const uint32_t by = i / width_in_blocks, bx = i - by * width_in_blocks;
+	uint32_t by, bx;
+	split_index(i, width_in_blocks, by, bx);
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
 		const uint32_t y = by * 4u + r;

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	if (i >= lv.n_blocks) return;
 	uint32_t o[4 * ROW];
 	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
-	const uint32_t by = i / lv.width_in_blocks, bx = i - by * lv.width_in_blocks;
+	uint32_t by, bx;
+	split_index(i, lv.width_in_blocks, by, bx);
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
 	if (lv.fast) {
 #pragma unroll

@@ -41,6 +41,8 @@ extern "C" int emul_decode_blocks(int fmt, const uint8_t *in, long n, uint32_t m
 	case 7: run<DecRGTC2>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 8: run<DecSignedRGTC2>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 9: run<DecBPTCFloat>(in, n, mode_mask, flags, checked, out, ok); break;
+	case 109: run<DecBPTCFloatT<false, true>>(in, n, mode_mask, flags, checked, out, ok); break;
+	case 110: run<DecBPTCFloatT<true, true>>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 10: run<DecBPTCSignedFloat>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 11: run<DecBPTC>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 12: run<DecETC1>(in, n, mode_mask, flags, checked, out, ok); break;
