@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--format", default="BC1")
     ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
+    ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (include/detexhip.h)")
     ap.add_argument("--stream", default="U", choices=["U", "M"])
     ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
@@ -122,10 +123,17 @@ def main():
     if not torch.cuda.is_available():
         log("bench.py: no HIP device; the decode path has no CPU fallback")
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    # DETEX_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (all ranks share
+    # cuda:0; a plumbing test, not a measurement).  The driver's runs use RCCL ("nccl").
+    backend = os.environ.get("DETEX_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     binding.load()
     binding.set_kernel_variant(args.variant)
 
@@ -168,13 +176,15 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
         if world > 1:
-            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, ev_ms = t.tolist()
         return data, d_blocks, d_out, wall, ev_ms / steps
 
     fmt = F.BY_NAME[args.format]
     W = H = args.size
+    if args.band_height:
+        H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
     data, d_blocks, d_out, wall, launch_ms = run_format(fmt, W, H, args.steps, args.warmup)
     blocks = (W // 4) * (H // 4)
     pf, tpx = target_of(fmt)

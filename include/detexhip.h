@@ -43,7 +43,11 @@ DETEXHIP_API const char *detexhipVersion(void);
  *                    Rows are written with 16-byte vector stores when width%4 == 0, d_pixels
  *                    and pitch_bytes are 16-byte aligned; any other geometry takes the clipped
  *                    per-pixel path (d_pixels, pitch_bytes aligned to the pixel size).
- *   pixel_format     native pixel format of texture_format, or RGBA8/RGBX8 for either
+ *   pixel_format     native pixel format of texture_format; RGBA8/RGBX8 for either (the no-op
+ *                    edge, convert.c:768-769); and, converted inside the kernel exactly as
+ *                    detexConvertPixels would (convert.c:37-70,671-684): BGRA8, BGRX8, RGB8
+ *                    for formats whose native target is RGBA8/RGBX8, FLOAT_BGRX16 for
+ *                    BPTC_FLOAT.  Anything else is refused (rc != 0, nothing is written).
  *   d_status         optional device uint32_t: set to 1 by the kernel if any block was invalid
  *                    (those blocks are zero-filled, decoding continues: texture.c:125-128).
  *                    The caller zeroes it beforehand and reads it after synchronising;
@@ -103,7 +107,8 @@ DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *
 /* Kernel-variant selection for A/B measurements (bench.py --variant):
  *   0  lane-per-block, 64x1-block wave tiles, non-temporal row stores (default)
  *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 only]
- *   2  as 0 with ordinary (cached) row stores
+ *   2  as 0 with ordinary (cached) row stores (and no LDS row transpose for 64-bit pixels)
+ *   3  as 0, BPTC_FLOAT field scatter as a per-mode switch instead of descriptor words
  * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);
