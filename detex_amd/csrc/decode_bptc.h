@@ -75,9 +75,24 @@ DH BlendPair blend_pair(uint32_t e0, uint32_t e1) {
 	return p;
 }
 
+// Weight of an n-bit index as one multiply-add: t = (64*i + d/2) * ceil(65536/d) < 2^24 and the
+// weight is byte 2 of t (bptc-tables.c aWeight2/3/4 in closed form, proven in tests/test_host_logic.py).
+struct WeightMad { uint32_t mul, add; };
+DH WeightMad weight_mad(uint32_t bits) {
+	WeightMad w;
+	w.mul = bits == 2 ? 1398144u : (bits == 3 ? 599232u : 279680u);
+	w.add = bits == 2 ? 21846u : (bits == 3 ? 28089u : 30590u);
+	return w;
+}
+
 // FIXED_MODE >= 0 instantiates the decoder for one mode with every layout parameter a compile-time
 // constant (used by wave-uniform fast paths); FIXED_MODE = -1 is the per-lane data-driven form.
-template <int FIXED_MODE> struct DecBPTCMode {
+// IMPL selects the texel stage (A/B):
+//   0  subset endpoints picked per texel with v_bfi_b32 chains (registers only)
+//   1  subset endpoints kept in per-lane LDS rows, one ds_read_b128 per texel; colour / alpha index
+//      streams (instead of primary / secondary + per-texel swaps); weights by one v_mad_u32_u24
+//   2  as 1, and block fields are fetched from an LDS copy of the block (two dwords + v_alignbit)
+template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
 
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
@@ -98,6 +113,16 @@ template <int FIXED_MODE> struct DecBPTCMode {
 		const uint32_t cb = ubfe(desc, 8, 3), ab = ubfe(desc, 11, 4), epb = ubfe(desc, 15, 1), spb = ubfe(desc, 16, 1);
 		const uint32_t ib = ubfe(desc, 17, 3), ib2 = ubfe(desc, 20, 2);
 		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
+		// IMPL 2: the block's dwords as per-lane LDS rows (rows 4, 5 read as zero: bits beyond 127)
+		LaneRows<uint32_t, IMPL == 2 ? 6 : 1, 71> rows;
+		if (IMPL == 2) {
+			rows.put(0, blk.x); rows.put(1, blk.y); rows.put(2, blk.z); rows.put(3, blk.w); rows.put(4, 0u); rows.put(5, 0u);
+		}
+		auto field32 = [&](uint32_t at) -> uint32_t {
+			if (IMPL != 2) return extract32(b, at);
+			const uint32_t k = at >> 5;
+			return __builtin_amdgcn_alignbit(rows.get(k + 1u), rows.get(k), at);
+		};
 
 		// header fields all lie in the first 14 bits
 		uint32_t pos = mode + 1u;
@@ -107,11 +132,11 @@ template <int FIXED_MODE> struct DecBPTCMode {
 
 		// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values) -- :74-132
 		const uint32_t chan = 2u * ns * cb;			// <= 30 bits per colour channel
-		const uint32_t wr = extract32(b, pos), wg = extract32(b, pos + chan), wb = extract32(b, pos + 2u * chan);
+		const uint32_t wr = field32(pos), wg = field32(pos + chan), wb = field32(pos + 2u * chan);
 		pos += 3u * chan;
-		const uint32_t wa = extract32(b, pos);
+		const uint32_t wa = field32(pos);
 		pos += 2u * ns * ab;
-		uint32_t pw = extract32(b, pos);			// P-bits: per endpoint, or per subset (mode 1)
+		uint32_t pw = field32(pos);				// P-bits: per endpoint, or per subset (mode 1)
 		pw = mode == 6u ? (pw & 1u) : pw;			// QUIRK A-2 (decompress-bptc.c:142-146)
 		pos += epb * 2u * ns + spb * ns;
 
@@ -121,67 +146,134 @@ template <int FIXED_MODE> struct DecBPTCMode {
 		const uint32_t c_up = 8u - cprec, c_down = (2u * cprec - 8u) & 31u;
 		const uint32_t a_up = (8u - aprec) & 31u, a_down = (2u * aprec - 8u) & 31u;
 		const uint32_t c_keep = 0x010101u * ((1u << c_up) - 1u);
+		// P-bit of endpoint e at bit e: per-endpoint P-bits as stored, a shared P-bit (mode 1) doubled
+		const uint32_t pw_e = (epb ? pw : ((pw & 1u) * 3u) | ((pw & 2u) * 6u)) & (0u - has_p);
 		uint32_t ep[6];
 #pragma unroll
 		for (int e = 0; e < 6; e++) {
 			const uint32_t off = (uint32_t)e * cb, offa = (uint32_t)e * ab;
 			uint32_t x = ubfe(wr, off, cb) | (ubfe(wg, off, cb) << 8) | (ubfe(wb, off, cb) << 16);
-			const uint32_t p = ubfe(pw, epb ? (uint32_t)e : (uint32_t)(e >> 1), 1) & has_p;
+			const uint32_t p = ubfe(pw_e, e, 1);
 			x = (x << has_p) | ((0u - p) & 0x010101u);
 			x = ((x << c_up) | ((x >> c_down) & c_keep)) & 0xFFFFFFu;
-			uint32_t a = ubfe(wa, offa, ab);
-			a = (a << epb) | (p & epb);
-			a = ((a << a_up) | (a >> a_down)) & 0xFFu;
-			a = mode < 4u ? 0xFFu : a;			// :176-179
+			uint32_t a = 0xFFu;					// :176-179; modes with alpha have at most two subsets
+			if (e < 4) {
+				a = ubfe(wa, offa, ab);
+				a = (a << epb) | (p & epb);
+				a = ((a << a_up) | (a >> a_down)) & 0xFFu;
+				a = mode < 4u ? 0xFFu : a;
+			}
 			ep[e] = x | (a << 24);
 		}
-		const BlendPair s0 = blend_pair(ep[0], ep[1]), s1 = blend_pair(ep[2], ep[3]), s2 = blend_pair(ep[4], ep[5]);
 
 		// partition + anchors (:391-400)
 		const uint32_t pword = ns == 1u ? 0u : kPartition2Bit[part + (ns == 3u ? 64u : 0u)];
 		const uint32_t an = kAnchorWords[part];
 		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
 		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
-
-		// index streams, consumed LSB-first: primary (16*ib - ns bits), then, for modes 4/5, the
-		// secondary one (16*ib2 - 1 bits) -- :401-480.  Each is a {hi,lo} pair advanced by funnel shifts.
-		uint32_t plo = extract32(b, pos), phi = extract32(b, pos + 32u);
+		// gather the high bytes of the four 16-bit sums; rotation swaps A with R/G/B (:497-508)
+		const uint32_t gather = rot == 0u ? 0x07050301u : (rot == 1u ? 0x01050307u : (rot == 2u ? 0x03050701u : 0x05070301u));
+		// index streams, LSB-first: primary (16*ib - ns bits), then, for modes 4/5, the secondary one
+		// (16*ib2 - 1 bits) -- :401-480
 		const uint32_t pos2 = pos + 16u * ib - ns;
 		const bool two = ib2 != 0u, swap = two && isel != 0u;
 		const bool any_two = FIXED_MODE >= 0 ? (FIXED_MODE == 4 || FIXED_MODE == 5) : (__builtin_amdgcn_ballot_w64(two) != 0);
-		uint32_t slo = 0, shi = 0;
-		if (any_two) { slo = extract32(b, pos2); shi = extract32(b, pos2 + 32u); }
-		// colour uses the secondary indices when the index-selection bit is set (:374-375, 452-480)
-		const WeightParams wp_a = weight_params(ib), wp_b = weight_params(two ? ib2 : ib);
-		// gather the high bytes of the four 16-bit sums; rotation swaps A with R/G/B (:497-508)
-		const uint32_t gather = rot == 0u ? 0x07050301u : (rot == 1u ? 0x01050307u : (rot == 2u ? 0x03050701u : 0x05070301u));
 
+		if (IMPL == 0) {
+			const BlendPair s0 = blend_pair(ep[0], ep[1]), s1 = blend_pair(ep[2], ep[3]), s2 = blend_pair(ep[4], ep[5]);
+			uint32_t plo = extract32(b, pos), phi = extract32(b, pos + 32u);
+			uint32_t slo = 0, shi = 0;
+			if (any_two) { slo = extract32(b, pos2); shi = extract32(b, pos2 + 32u); }
+			// colour uses the secondary indices when the index-selection bit is set (:374-375, 452-480)
+			const WeightParams wp_a = weight_params(ib), wp_b = weight_params(two ? ib2 : ib);
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			const uint32_t width = ib - ((amask >> i) & 1u);	// anchor texels store one bit less
-			const uint32_t w_a = weight_of(ubfe(plo, 0, width), wp_a);
-			plo = __builtin_amdgcn_alignbit(phi, plo, width);
-			phi >>= width;
-			uint32_t w_rg = DETEX_UMUL24(w_a, 0x00040004u), w_ba = w_rg;	// 4*w in both 16-bit lanes
-			if (any_two) {
-				const uint32_t width2 = (ib2 - (i == 0 ? 1u : 0u)) & 31u;
-				const uint32_t w_b = two ? weight_of(ubfe(slo, 0, width2), wp_b) : w_a;
-				slo = __builtin_amdgcn_alignbit(shi, slo, width2);
-				shi >>= width2;
-				const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
-				w_rg = DETEX_UMUL24(wc, 0x00040004u);
-				w_ba = (wc | (wal << 16)) << 2;
+			for (int i = 0; i < 16; i++) {
+				const uint32_t width = ib - ((amask >> i) & 1u);	// anchor texels store one bit less
+				const uint32_t w_a = weight_of(ubfe(plo, 0, width), wp_a);
+				plo = __builtin_amdgcn_alignbit(phi, plo, width);
+				phi >>= width;
+				uint32_t w_rg = DETEX_UMUL24(w_a, 0x00040004u), w_ba = w_rg;	// 4*w in both 16-bit lanes
+				if (any_two) {
+					const uint32_t width2 = (ib2 - (i == 0 ? 1u : 0u)) & 31u;
+					const uint32_t w_b = two ? weight_of(ubfe(slo, 0, width2), wp_b) : w_a;
+					slo = __builtin_amdgcn_alignbit(shi, slo, width2);
+					shi >>= width2;
+					const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
+					w_rg = DETEX_UMUL24(wc, 0x00040004u);
+					w_ba = (wc | (wal << 16)) << 2;
+				}
+				const uint32_t m1 = bit_to_mask(pword, 2 * i), m2 = bit_to_mask(pword, 2 * i + 1);
+				const uint32_t base_rg = bfi(m2, s2.base_rg, bfi(m1, s1.base_rg, s0.base_rg));
+				const uint32_t base_ba = bfi(m2, s2.base_ba, bfi(m1, s1.base_ba, s0.base_ba));
+				const uint32_t diff_rg = bfi(m2, s2.diff_rg, bfi(m1, s1.diff_rg, s0.diff_rg));
+				const uint32_t diff_ba = bfi(m2, s2.diff_ba, bfi(m1, s1.diff_ba, s0.diff_ba));
+				d[i] = perm(pk_mad_u16(diff_ba, w_ba, base_ba), pk_mad_u16(diff_rg, w_rg, base_rg), gather);
 			}
-			const uint32_t m1 = bit_to_mask(pword, 2 * i), m2 = bit_to_mask(pword, 2 * i + 1);
-			const uint32_t base_rg = bfi(m2, s2.base_rg, bfi(m1, s1.base_rg, s0.base_rg));
-			const uint32_t base_ba = bfi(m2, s2.base_ba, bfi(m1, s1.base_ba, s0.base_ba));
-			const uint32_t diff_rg = bfi(m2, s2.diff_rg, bfi(m1, s1.diff_rg, s0.diff_rg));
-			const uint32_t diff_ba = bfi(m2, s2.diff_ba, bfi(m1, s1.diff_ba, s0.diff_ba));
-			d[i] = perm(pk_mad_u16(diff_ba, w_ba, base_ba), pk_mad_u16(diff_rg, w_rg, base_rg), gather);
+			return true;
+		}
+
+		// ---- IMPL 1 / 2 ----
+		// per-subset blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba} as LDS rows of this lane
+		LaneRows<uint4, 3, 72> subsets;
+#pragma unroll
+		for (int s = 0; s < 3; s++) {
+			const uint32_t e0 = ep[2 * s], e1 = ep[2 * s + 1];
+			const uint32_t rg0 = perm(0u, e0, 0x0C010C00u), ba0 = perm(0u, e0, 0x0C030C02u);
+			const uint32_t rg1 = perm(0u, e1, 0x0C010C00u), ba1 = perm(0u, e1, 0x0C030C02u);
+			uint4 row;
+			row.x = (rg0 << 8) | 0x00800080u;
+			row.y = (ba0 << 8) | 0x00800080u;
+			row.z = pk_sub_u16(rg1 << 2, rg0 << 2);		// 4*(e1-e0) per 16-bit lane (mod 2^16)
+			row.w = pk_sub_u16(ba1 << 2, ba0 << 2);
+			subsets.put(s, row);
+		}
+		// colour stream C and alpha stream A: C is the primary stream unless the index-selection bit
+		// swaps them (:374-375, 452-480); only modes 4/5 have an A stream (one subset, anchor = texel 0)
+		const uint32_t ibc = swap ? ib2 : ib, iba = swap ? ib : ib2;
+		const uint32_t pos_c = swap ? pos2 : pos, pos_a = swap ? pos : pos2;
+		// Each stream is read through two 32-bit windows: texels 0-7 consume at most 31 bits (texel 0 is
+		// always an anchor), texels 8-15 start where they ended -- so advancing a stream is one plain shift.
+		const uint32_t half_c = 8u * ibc - (uint32_t)__builtin_popcount(amask & 0xFFu);
+		const uint32_t c_lo = field32(pos_c), c_hi = field32(pos_c + half_c);
+		const WeightMad wm_c = weight_mad(ibc);
+		// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
+		if (any_two) {
+			const uint32_t half_a = (8u * iba - 1u) & 31u;
+			const uint32_t a_lo = field32(pos_a), a_hi = field32(pos_a + half_a);
+			const WeightMad wm_a = weight_mad(iba);
+			const uint32_t sel_ba = two ? 0x0C060C02u : 0x0C020C02u;	// alpha weight from the A stream, or the colour weight again
+			const uint32_t width_a = iba & 31u;
+			uint32_t cw = c_lo, aw = a_lo;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				if (i == 8) { cw = c_hi; aw = a_hi; }
+				const uint32_t width = ibc - ((amask >> i) & 1u);	// anchor texels store one bit less
+				const uint32_t tc = DETEX_UMUL24(ubfe(cw, 0, width), wm_c.mul) + wm_c.add;	// weight = byte 2
+				cw >>= width;
+				const uint32_t wa = i == 0 ? ((iba - 1u) & 31u) : width_a;
+				const uint32_t ta = DETEX_UMUL24(ubfe(aw, 0, wa), wm_a.mul) + wm_a.add;
+				aw >>= wa;
+				const uint4 s = subsets.get(ubfe(pword, 2 * i, 2));
+				d[i] = perm(pk_mad_u16(s.w, perm(ta, tc, sel_ba), s.y), pk_mad_u16(s.z, perm(tc, tc, 0x0C020C02u), s.x), gather);
+			}
+		} else {
+			uint32_t cw = c_lo;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				if (i == 8) cw = c_hi;
+				const uint32_t width = ibc - ((amask >> i) & 1u);
+				const uint32_t tc = DETEX_UMUL24(ubfe(cw, 0, width), wm_c.mul) + wm_c.add;
+				cw >>= width;
+				const uint32_t w = perm(tc, tc, 0x0C020C02u);		// weight in both 16-bit lanes
+				const uint4 s = subsets.get(ubfe(pword, 2 * i, 2));
+				d[i] = perm(pk_mad_u16(s.w, w, s.y), pk_mad_u16(s.z, w, s.x), gather);
+			}
 		}
 		return true;
 	}
 };
 using DecBPTC = DecBPTCMode<-1>;
+using DecBPTCRegisterSelect = DecBPTCMode<-1, 0>;
+using DecBPTCRegisterFields = DecBPTCMode<-1, 1>;
 
 }  // namespace detexhip

@@ -266,43 +266,54 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		const uint32_t pmask = two ? (uint32_t)kPartition1Bit[part] : 0u;
 		const uint32_t amask = 1u | (two ? (1u << (kAnchorWords[part] & 0xFu)) : 0u);
 		const uint32_t ibits = two ? 3u : 4u;
-		// index stream consumed LSB-first as a {hi,lo} pair advanced by funnel shifts
-		uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
-		uint32_t hi = two ? (blk.w >> 18) : (blk.w >> 1);
-		const WeightParams wp = weight_params(ibits);
+		// Index stream, LSB-first, read through two 32-bit windows: texels 0-7 consume 8*ibits - (anchors among
+		// them) <= 31 bits (texel 0 is always an anchor), texels 8-15 start where they ended, and that second window
+		// lies in the last dword (bit 96 / 104 / 105) -- so advancing the stream is one plain shift per texel.
+		const uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
+		const uint32_t hi = blk.w >> (two ? 10u - (uint32_t)__builtin_popcount(amask & 0xFFu) : 0u);
+		const WeightMad wm = weight_mad(ibits);
 		// ((64-w)*e0 + w*e1 + 32) >> 6  ==  (64*e0 + 32 + w*(e1-e0)) >> 6  (:97-108): per subset keep
-		// base = 64*e0 + 32 and diff = e1 - e0, so a texel channel is one v_mad_i32_i24 + one shift
-		int32_t base[3][2], diff[3][2];
+		// base = 64*e0 + 32 and diff = e1 - e0 (a texel channel is one v_mad_i32_i24 + one shift) in per-lane LDS
+		// rows, fetched per texel by the partition bit (dev_common.h: LaneRows)
+		LaneRows<uint4, 2, 81> row_a;		// base r, g, b, diff r
+		LaneRows<uint2, 2, 82> row_b;		// diff g, b
 #pragma unroll
-		for (int c = 0; c < 3; c++)
-#pragma unroll
-			for (int s = 0; s < 2; s++) {
-				base[c][s] = q[c][2 * s] * 64 + 32;
-				diff[c][s] = q[c][2 * s + 1] - q[c][2 * s];
-			}
+		for (int s = 0; s < 2; s++) {
+			uint4 ra; uint2 rb;
+			ra.x = (uint32_t)(q[0][2 * s] * 64 + 32);
+			ra.y = (uint32_t)(q[1][2 * s] * 64 + 32);
+			ra.z = (uint32_t)(q[2][2 * s] * 64 + 32);
+			ra.w = (uint32_t)(q[0][2 * s + 1] - q[0][2 * s]);
+			rb.x = (uint32_t)(q[1][2 * s + 1] - q[1][2 * s]);
+			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
+			row_a.put(s, ra);
+			row_b.put(s, rb);
+		}
+		uint32_t win = lo;
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
+			if (i == 8) win = hi;
 			const uint32_t width = ibits - ((amask >> i) & 1u);	// anchor texels store one bit less
-			const int32_t w = (int32_t)weight_of(ubfe(lo, 0, width), wp);
-			lo = __builtin_amdgcn_alignbit(hi, lo, width);
-			hi >>= width;
-			const uint32_t ms = bit_to_mask(pmask, i);
+			const int32_t w = (int32_t)((DETEX_UMUL24(ubfe(win, 0, width), wm.mul) + wm.add) >> 16);
+			win >>= width;
+			const uint32_t sub = (pmask >> i) & 1u;
+			const uint4 ra = row_a.get(sub);
+			const uint2 rb = row_b.get(sub);
+			const int32_t bs[3] = { (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z }, df[3] = { (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y };
 			uint32_t h[3];
 #pragma unroll
 			for (int c = 0; c < 3; c++) {
-				const int32_t bs = (int32_t)bfi(ms, (uint32_t)base[c][1], (uint32_t)base[c][0]);
-				const int32_t df = (int32_t)bfi(ms, (uint32_t)diff[c][1], (uint32_t)diff[c][0]);
-				const int32_t v = (bs + __mul24(w, df)) >> 6;
+				const int32_t v = (bs[c] + __mul24(w, df[c])) >> 6;
 				if (SIGNED) {				// :576-609 sign-magnitude half: m = (|v|*31)>>5, sign only if m != 0
-					const uint32_t m = (uint32_t)__mul24(max(v, -v), 31) >> 5;
-					const uint32_t hs = m | (((uint32_t)v >> 16) & 0x8000u);
-					h[c] = m ? hs : 0u;
+					const uint32_t sg = (uint32_t)(v >> 31);
+					const uint32_t m = (uint32_t)__mul24((int32_t)(((uint32_t)v ^ sg) - sg), 31) >> 5;	// m <= 0x7BFF
+					h[c] = m | ((m + 0x7FFFu) & sg & 0x8000u);	// bit 15 of m + 0x7FFF is set iff m != 0
 				} else {
 					h[c] = (uint32_t)__mul24(v, 31) >> 6;	// :613-621 (v >= 0: /64 == >>6)
 				}
 			}
 			d[2 * i] = perm(h[1], h[0], 0x05040100u);	// every h < 2^16; v_perm keeps the compiler from fusing
-									// the shift into a (40x slower) v_mul_lo_u32
+									// the shift into a v_mul_lo_u32
 			d[2 * i + 1] = h[2];				// X = 0
 		}
 		return true;

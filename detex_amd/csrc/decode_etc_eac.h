@@ -33,20 +33,31 @@ __constant__ uint16_t kEacMagnitudes[16] = {
 	0xA862, 0xA852, 0xA842, 0xA752, 0xA743, 0xA321, 0x9864, 0x9753,
 };
 
-DH uint32_t etc_entry(int32_t r, int32_t g, int32_t b, int32_t m, uint32_t alpha) {
-	return pack_rgba(clamp255(r + m), clamp255(g + m), clamp255(b + m), 0u) | alpha;
-}
 DH uint32_t rep4(uint32_t v) { return v | (v << 4); }
+
+// Arithmetic of this file runs two signed 16-bit lanes per VGPR (dev_common.h: pk_add16 / pk_sub16 /
+// pk_ashr16 / sat_u8_pk16): a colour is held as RB = (R, B) lanes plus G, where the G's of two
+// colours (or of two neighbouring texels) share one register.  sat_u8_pk16 is the 0..255 clamp of both
+// lanes and leaves them in bytes 0, 1, from where one v_perm_b32 assembles an RGBA texel (selector
+// byte 0x0D yields the opaque alpha 0xFF, 0x0C yields 0).
+template <uint32_t ALPHA> struct EtcGather {
+	static constexpr uint32_t kA = ALPHA ? 0x0D000000u : 0x0C000000u;
+	// rb: R in byte 0, B in byte 1 (saturated form); g: G in byte GB of g
+	template <int GB> static DH uint32_t sat(uint32_t g, uint32_t rb) { return perm(g, rb, kA | 0x00010000u | ((4u + GB) << 8)); }
+	// rb: unsaturated lanes (R in byte 0, B in byte 2); g lanes likewise (G in byte 0 or 2)
+	template <int GB> static DH uint32_t raw(uint32_t g, uint32_t rb) { return perm(g, rb, kA | 0x00020000u | ((4u + GB) << 8)); }
+};
 
 // texel loop shared by every non-planar mode.  pal0 = sub-block 0 palette, pal1 = sub-block 1;
 // flip selects the 2x4 / 4x2 split (decompress-etc.c:143-178).  Texel p is column-major
 // (x = p>>2, y = p&3) and lands at row-major index y*4+x (decompress-etc.c:83).
 DH void etc_texels(uint32_t word, bool flip, const uint32_t (&pal0)[4], const uint32_t (&pal1)[4], uint32_t (&d)[16]) {
 	uint32_t palb[4], palc[4];	// quadrant (x<2,y>=2) and (x>=2,y<2)
+	const uint32_t fm = cond_to_mask(flip);
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		palb[k] = flip ? pal1[k] : pal0[k];
-		palc[k] = flip ? pal0[k] : pal1[k];
+		palb[k] = bfi(fm, pal1[k], pal0[k]);
+		palc[k] = bfi(fm, pal0[k], pal1[k]);
 	}
 #pragma unroll
 	for (int p = 0; p < 16; p++) {
@@ -57,12 +68,15 @@ DH void etc_texels(uint32_t word, bool flip, const uint32_t (&pal0)[4], const ui
 	}
 }
 
-// KIND: 0 = ETC1, 1 = ETC2, 2 = ETC2 punchthrough.  ALPHA = alpha bits OR-ed into opaque texels
+// KIND: 0 = ETC1, 1 = ETC2, 2 = ETC2 punchthrough.  ALPHA = alpha bits of opaque texels
 // (0xFF000000, or 0 when an EAC alpha plane is merged afterwards).
 // decompress-etc.c:89-180 (ETC1), :202-367 (ETC2), :472-717 (punchthrough).
 template <int KIND, uint32_t ALPHA, bool CHECKED>
 DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
+	static_assert(ALPHA == 0u || ALPHA == 0xFF000000u, "alpha is all-or-nothing");
+	typedef EtcGather<ALPHA> G;
 	const uint32_t b0 = w0 & 0xFFu, b1 = (w0 >> 8) & 0xFFu, b2 = (w0 >> 16) & 0xFFu, b3 = w0 >> 24;
+	const uint32_t W = bswap32(w0);			// b0 in bits 31:24 ... b3 in bits 7:0
 	const uint32_t word = bswap32(w1);
 	const bool diffbit = (b3 & 2u) != 0;		// ETC1/ETC2: differential; punchthrough: opaque
 	// 5-bit base + 3-bit two's-complement delta; out of 0..31 selects T / H / planar (:324-366)
@@ -94,97 +108,100 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 		}
 	}
 	if (mode_planar) {
-		// :287-317: O, H, V in 6-7-6, MSB-replicated to 8 bits; texel = clamp((x(H-O) + y(V-O) + 4O + 2) >> 2)
-		const uint32_t b4 = word >> 24, b5 = (word >> 16) & 0xFFu, b6 = (word >> 8) & 0xFFu, b7 = word & 0xFFu;
-		int32_t o[3], h[3], v[3];
-		o[0] = (b0 & 0x7Eu) >> 1;
-		o[1] = ((b0 & 1u) << 6) | ((b1 & 0x7Eu) >> 1);
-		o[2] = ((b1 & 1u) << 5) | (b2 & 0x18u) | ((b2 & 3u) << 1) | (b3 >> 7);
-		h[0] = ((b3 & 0x7Cu) >> 1) | (b3 & 1u);
-		h[1] = b4 >> 1;
-		h[2] = ((b4 & 1u) << 5) | (b5 >> 3);
-		v[0] = ((b5 & 7u) << 3) | (b6 >> 5);
-		v[1] = ((b6 & 0x1Fu) << 2) | (b7 >> 6);
-		v[2] = b7 & 0x3Fu;
+		// :287-317: O, H, V in 6-7-6 bits, MSB-replicated to 8; texel = clamp255((x(H-O) + y(V-O) + 4O + 2) >> 2).
+		// Every term fits a signed 16-bit lane (|sum| <= 2550), so a texel is three packed adds shared
+		// between channels / neighbours, an arithmetic shift and the saturating pack.
+		const uint32_t ro = (W >> 25) & 0x3Fu, go = ((W >> 18) & 0x40u) | ((W >> 17) & 0x3Fu);
+		const uint32_t bo = ((W >> 11) & 0x20u) | ((W >> 8) & 0x18u) | ((W >> 7) & 0x7u);
+		const uint32_t rh = ((W >> 1) & 0x3Eu) | (W & 1u), gh = word >> 25, bh = (word >> 19) & 0x3Fu;
+		const uint32_t rv = (word >> 13) & 0x3Fu, gv = (word >> 6) & 0x7Fu, bv = word & 0x3Fu;
+		uint32_t o_rb = ro | (bo << 16), h_rb = rh | (bh << 16), v_rb = rv | (bv << 16);
+		o_rb = (o_rb << 2) | ((o_rb >> 4) & 0x00030003u);
+		h_rb = (h_rb << 2) | ((h_rb >> 4) & 0x00030003u);
+		v_rb = (v_rb << 2) | ((v_rb >> 4) & 0x00030003u);
+		const uint32_t o_g = (go << 1) | (go >> 6), h_g = (gh << 1) | (gh >> 6), v_g = (gv << 1) | (gv >> 6);
+		const uint32_t dh_rb = pk_sub16(h_rb, o_rb), dv_rb = pk_sub16(v_rb, o_rb);
+		const uint32_t dh_g = h_g - o_g, dv_g = v_g - o_g, o4_g = 4u * o_g + 2u;
+		uint32_t rb_row = (o_rb << 2) + 0x00020002u;		// 4*O + 2 in both lanes
+		uint32_t gg_row = pack16(o4_g, o4_g + dh_g);		// G of texels x = 0, 1
+		const uint32_t gg_dv = pack16(dv_g, dv_g), gg_2dh = pack16(2u * dh_g, 2u * dh_g);
 #pragma unroll
-		for (int k = 0; k < 3; k++) {
-			const int s = (k == 1) ? 1 : 2, t = (k == 1) ? 6 : 4;
-			o[k] = (o[k] << s) | (o[k] >> t);
-			h[k] = (h[k] << s) | (h[k] >> t);
-			v[k] = (v[k] << s) | (v[k] >> t);
-			h[k] -= o[k];
-			v[k] -= o[k];
-			o[k] = 4 * o[k] + 2;
+		for (int y = 0; y < 4; y++) {
+			if (y) { rb_row = pk_add16(rb_row, dv_rb); gg_row = pk_add16(gg_row, gg_dv); }
+			const uint32_t g01 = sat_u8_pk16(pk_ashr16(gg_row, 2)), g23 = sat_u8_pk16(pk_ashr16(pk_add16(gg_row, gg_2dh), 2));
+			uint32_t rb = rb_row;
+			d[y * 4 + 0] = G::template sat<0>(g01, sat_u8_pk16(pk_ashr16(rb, 2)));
+			rb = pk_add16(rb, dh_rb);
+			d[y * 4 + 1] = G::template sat<1>(g01, sat_u8_pk16(pk_ashr16(rb, 2)));
+			rb = pk_add16(rb, dh_rb);
+			d[y * 4 + 2] = G::template sat<0>(g23, sat_u8_pk16(pk_ashr16(rb, 2)));
+			rb = pk_add16(rb, dh_rb);
+			d[y * 4 + 3] = G::template sat<1>(g23, sat_u8_pk16(pk_ashr16(rb, 2)));
 		}
-		// clamp255(s >> 2) is written as clampi(s, 0, 1023) >> 2 (identical for every int s).
-		// Besides saving nothing or costing nothing, this form matters: for the pair pattern
-		// clamp(a >> 2) | clamp(b >> 2) << 8, hipcc 7.2 selects gfx950's v_ashr_pk_u8_i32 and ORs the
-		// result as if it were zero-extended, but on MI355X its bits [31:16] are not zero -- the
-		// blue byte came out corrupted (found by the parity tests; see DESIGN.md "toolchain notes").
-#pragma unroll
-		for (int y = 0; y < 4; y++)
-#pragma unroll
-			for (int x = 0; x < 4; x++)
-				d[y * 4 + x] = pack_rgba((uint32_t)clampi(x * h[0] + y * v[0] + o[0], 0, 1023) >> 2,
-					(uint32_t)clampi(x * h[1] + y * v[1] + o[1], 0, 1023) >> 2,
-					(uint32_t)clampi(x * h[2] + y * v[2] + o[2], 0, 1023) >> 2, 0u) | ALPHA;
 		return true;
 	}
 	uint32_t pal0[4], pal1[4];
 	bool flip = (b3 & 1u) != 0;
 	if (mode_t || mode_h) {
-		// :202-285 / :565-649: two RGB444 base colours +- distance -> four paint colours
-		int32_t c1r, c1g, c1b, c2r, c2g, c2b, dist;
-		if (mode_t) {
-			c1r = rep4(((b0 & 0x18u) >> 1) | (b0 & 3u)); c1g = rep4(b1 >> 4); c1b = rep4(b1 & 0xFu);
-			c2r = rep4(b2 >> 4); c2g = rep4(b2 & 0xFu); c2b = rep4(b3 >> 4);
-			dist = perm(ETC_DIST_HI, ETC_DIST_LO, ((b3 & 0xCu) >> 1) | (b3 & 1u)) & 0xFFu;
-			pal0[0] = pack_rgba(c1r, c1g, c1b, 0u) | ALPHA;
-			pal0[1] = etc_entry(c2r, c2g, c2b, dist, ALPHA);
-			pal0[2] = pack_rgba(c2r, c2g, c2b, 0u) | ALPHA;
-			pal0[3] = etc_entry(c2r, c2g, c2b, -dist, ALPHA);
-		} else {
-			c1r = rep4((b0 & 0x78u) >> 3);
-			c1g = rep4(((b0 & 7u) << 1) | ((b1 & 0x10u) >> 4));
-			c1b = rep4((b1 & 8u) | ((b1 & 3u) << 1) | (b2 >> 7));
-			c2r = rep4((b2 & 0x78u) >> 3);
-			c2g = rep4(((b2 & 7u) << 1) | (b3 >> 7));
-			c2b = rep4((b3 & 0x78u) >> 3);
-			const uint32_t v1 = (c1r << 16) + (c1g << 8) + c1b, v2 = (c2r << 16) + (c2g << 8) + c2b;
-			dist = perm(ETC_DIST_HI, ETC_DIST_LO, (b3 & 4u) | ((b3 & 1u) << 1) | (v1 >= v2 ? 1u : 0u)) & 0xFFu;
-			pal0[0] = etc_entry(c1r, c1g, c1b, dist, ALPHA);
-			pal0[1] = etc_entry(c1r, c1g, c1b, -dist, ALPHA);
-			pal0[2] = etc_entry(c2r, c2g, c2b, dist, ALPHA);
-			pal0[3] = etc_entry(c2r, c2g, c2b, -dist, ALPHA);
-		}
+		// :202-285 / :565-649: two RGB444 base colours and a distance -> four paint colours.
+		// Both layouts are reduced to 12-bit colours c1, c2 (r<<8 | g<<4 | b) and a distance index, then share
+		// the arithmetic:  T = {c1, c2+d, c2, c2-d},  H = {c1+d, c1-d, c2+d, c2-d}.
+		const uint32_t c1_t = ((W >> 17) & 0xC00u) | ubfe(W, 16, 10);
+		const uint32_t c1_h = ((W >> 19) & 0xFE0u) | ((W >> 16) & 0x18u) | ((W >> 15) & 0x7u);
+		const uint32_t c1 = mode_t ? c1_t : c1_h;
+		const uint32_t c2 = ubfe(W, mode_t ? 4u : 3u, 12);
+		// H orders by the 24-bit expanded colours (:236); nibble replication is monotonic, so c1 >= c2 decides the same
+		const uint32_t di_t = ((b3 & 0xCu) >> 1) | (b3 & 1u), di_h = (b3 & 4u) | ((b3 & 1u) << 1) | (c1 >= c2 ? 1u : 0u);
+		const uint32_t di = mode_t ? di_t : di_h;
+		const uint32_t dd = perm(ETC_DIST_HI, ETC_DIST_LO, DETEX_UMUL24(di, 0x10001u) | 0x0C000C00u);	// (dist, dist)
+		const uint32_t rb1 = DETEX_UMUL24((c1 >> 8) | ((c1 & 0xFu) << 16), 17u), rb2 = DETEX_UMUL24((c2 >> 8) | ((c2 & 0xFu) << 16), 17u);
+		const uint32_t g12 = DETEX_UMUL24(ubfe(c1, 4, 4) | (ubfe(c2, 4, 4) << 16), 17u);	// (G1, G2)
+		const uint32_t gp = sat_u8_pk16(pk_add16(g12, dd)), gm = sat_u8_pk16(pk_sub16(g12, dd));
+		const uint32_t c1p = G::template sat<0>(gp, sat_u8_pk16(pk_add16(rb1, dd)));
+		const uint32_t c1m = G::template sat<0>(gm, sat_u8_pk16(pk_sub16(rb1, dd)));
+		const uint32_t c2p = G::template sat<1>(gp, sat_u8_pk16(pk_add16(rb2, dd)));
+		const uint32_t c2m = G::template sat<1>(gm, sat_u8_pk16(pk_sub16(rb2, dd)));
+		const uint32_t c1z = G::template raw<0>(g12, rb1), c2z = G::template raw<2>(g12, rb2);
+		const uint32_t tm = cond_to_mask(mode_t);
+		pal0[0] = bfi(tm, c1z, c1p);
+		pal0[1] = bfi(tm, c2p, c1m);
+		pal0[2] = bfi(tm, c2z, c2p);
+		pal0[3] = c2m;
 		if (!opaque) pal0[2] = 0u;		// punchthrough: selector 2 is fully transparent black (:483-499)
 #pragma unroll
 		for (int k = 0; k < 4; k++) pal1[k] = pal0[k];
 		flip = false;
 	} else {
-		// individual (4+4 bits, replicated) or differential (5 bits + signed 3-bit delta) bases
-		int32_t base0[3], base1[3];
-		const uint32_t byte[3] = { b0, b1, b2 };
-		const int32_t sum[3] = { sr, sg, sb };
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			const int32_t i0 = (byte[k] & 0xF0u) | (byte[k] >> 4), i1 = rep4(byte[k] & 0xFu);
-			const int32_t d0 = (byte[k] & 0xF8u) | (byte[k] >> 5), d1 = (sum[k] << 3) | (sum[k] >> 2);
-			base0[k] = individual ? i0 : d0;
-			base1[k] = individual ? i1 : d1;
-		}
-		const uint32_t t0 = (b3 >> 5) & 7u, t1 = (b3 >> 2) & 7u;
-		const int32_t s0 = opaque ? (int32_t)(perm(ETC_SMALL_HI, ETC_SMALL_LO, t0) & 0xFFu) : 0;
-		const int32_t s1 = opaque ? (int32_t)(perm(ETC_SMALL_HI, ETC_SMALL_LO, t1) & 0xFFu) : 0;
-		const int32_t l0 = perm(ETC_LARGE_HI, ETC_LARGE_LO, t0) & 0xFFu, l1 = perm(ETC_LARGE_HI, ETC_LARGE_LO, t1) & 0xFFu;
-		pal0[0] = etc_entry(base0[0], base0[1], base0[2], s0, ALPHA);
-		pal0[1] = etc_entry(base0[0], base0[1], base0[2], l0, ALPHA);
-		pal0[2] = etc_entry(base0[0], base0[1], base0[2], -s0, ALPHA);
-		pal0[3] = etc_entry(base0[0], base0[1], base0[2], -l0, ALPHA);
-		pal1[0] = etc_entry(base1[0], base1[1], base1[2], s1, ALPHA);
-		pal1[1] = etc_entry(base1[0], base1[1], base1[2], l1, ALPHA);
-		pal1[2] = etc_entry(base1[0], base1[1], base1[2], -s1, ALPHA);
-		pal1[3] = etc_entry(base1[0], base1[1], base1[2], -l1, ALPHA);
+		// individual (4+4 bits, replicated) or differential (5 bits + signed 3-bit delta) bases, all three
+		// channels at once in the bytes of x = R | G << 8 | B << 16 (:143-160)
+		const uint32_t x = w0 & 0xFFFFFFu;
+		const uint32_t i0 = (x & 0xF0F0F0u) | ((x >> 4) & 0x0F0F0Fu), i1 = (x & 0x0F0F0Fu) | ((x << 4) & 0xF0F0F0u);
+		const uint32_t d0 = (x & 0xF8F8F8u) | ((x >> 5) & 0x070707u);
+		// per byte: (b >> 3) + (b & 3) - (b & 4) = base + delta, in 0..31 for every block that reaches this path
+		// (an out-of-range sum selected T / H / planar, or failed ETC1, above), so no borrow crosses bytes
+		const uint32_t t = ((x >> 3) & 0x1F1F1Fu) + (x & 0x030303u) - (x & 0x040404u);
+		const uint32_t d1 = ((t << 3) & 0xF8F8F8u) | ((t >> 2) & 0x070707u);
+		const uint32_t im = cond_to_mask(individual);
+		const uint32_t base0 = bfi(im, i0, d0), base1 = bfi(im, i1, d1);
+		const uint32_t rb0 = perm(0u, base0, 0x0C020C00u), rb1 = perm(0u, base1, 0x0C020C00u);	// (R, B) lanes
+		const uint32_t g01 = perm(base1, base0, 0x0C050C01u);						// (G0, G1)
+		// intensity modifiers of both sub-blocks in one lookup each: (small0, small1), (large0, large1)
+		const uint32_t tsel = ubfe(b3, 5, 3) | (ubfe(b3, 2, 3) << 16) | 0x0C000C00u;
+		uint32_t s01 = perm(ETC_SMALL_HI, ETC_SMALL_LO, tsel);
+		const uint32_t l01 = perm(ETC_LARGE_HI, ETC_LARGE_LO, tsel);
+		if (!opaque) s01 = 0u;			// punchthrough non-opaque: modifiers {0, large, (transparent), -large}
+		const uint32_t s00 = perm(0u, s01, 0x01000100u), s11 = perm(0u, s01, 0x03020302u);
+		const uint32_t l00 = perm(0u, l01, 0x01000100u), l11 = perm(0u, l01, 0x03020302u);
+		const uint32_t gps = sat_u8_pk16(pk_add16(g01, s01)), gms = sat_u8_pk16(pk_sub16(g01, s01));
+		const uint32_t gpl = sat_u8_pk16(pk_add16(g01, l01)), gml = sat_u8_pk16(pk_sub16(g01, l01));
+		pal0[0] = G::template sat<0>(gps, sat_u8_pk16(pk_add16(rb0, s00)));
+		pal0[1] = G::template sat<0>(gpl, sat_u8_pk16(pk_add16(rb0, l00)));
+		pal0[2] = G::template sat<0>(gms, sat_u8_pk16(pk_sub16(rb0, s00)));
+		pal0[3] = G::template sat<0>(gml, sat_u8_pk16(pk_sub16(rb0, l00)));
+		pal1[0] = G::template sat<1>(gps, sat_u8_pk16(pk_add16(rb1, s11)));
+		pal1[1] = G::template sat<1>(gpl, sat_u8_pk16(pk_add16(rb1, l11)));
+		pal1[2] = G::template sat<1>(gms, sat_u8_pk16(pk_sub16(rb1, s11)));
+		pal1[3] = G::template sat<1>(gml, sat_u8_pk16(pk_sub16(rb1, l11)));
 		if (!opaque) { pal0[2] = 0u; pal1[2] = 0u; }
 	}
 	etc_texels(word, flip, pal0, pal1, d);

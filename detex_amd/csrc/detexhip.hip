@@ -80,6 +80,10 @@ template <class Dec> constexpr int target_class() {
 // alternative decoder implementations selectable for A/B measurements (kernel variant 3)
 template <class Dec> struct AltDecoder { using type = Dec; };
 template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };
+template <> struct AltDecoder<DecBPTC> { using type = DecBPTCRegisterSelect; };
+// second alternative (kernel variant 4)
+template <class Dec> struct AltDecoder2 { using type = Dec; };
+template <> struct AltDecoder2<DecBPTC> { using type = DecBPTCRegisterFields; };
 
 template <class Dec, int EPI> bool fast_geometry(const Geometry &g) {
 	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
@@ -96,8 +100,15 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 		if (EPI == kEpiNone && g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0)
 			return Tile4x4<Dec>::launch(g.blocks, px, g.wb, g.hb, g.pitch, g.status, g.stream);
 		if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder<Dec>::type, Dec>) {
-			if (g.variant == 3) {	// A/B: BC6H with the per-mode switch scatter instead of the divergence-free one
+			if (g.variant == 3) {	// A/B: BC6H per-mode switch scatter; BC7 register-select texel stage
 				hipLaunchKernelGGL((decode_linear<typename AltDecoder<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px,
+					g.wb, n, g.pitch, g.status);
+				return hipGetLastError();
+			}
+		}
+		if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder2<Dec>::type, Dec>) {
+			if (g.variant == 4) {	// A/B: BC7 with block fields extracted from registers (no LDS copy of the block)
+				hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px,
 					g.wb, n, g.pitch, g.status);
 				return hipGetLastError();
 			}
@@ -283,7 +294,7 @@ int current_variant() {
 	if (c.variant < 0) {
 		const char *env = getenv("DETEXHIP_VARIANT");
 		c.variant = env ? atoi(env) : 0;
-		if (c.variant < 0 || c.variant > 3) c.variant = 0;
+		if (c.variant < 0 || c.variant > 4) c.variant = 0;
 	}
 	return c.variant;
 }
@@ -348,7 +359,7 @@ extern "C" int detexhipSetDevice(int device) {
 
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
-extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 3) ? variant : 0; }
+extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 4) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
 
 extern "C" const char *detexhipKernelName(uint32_t texture_format) {

@@ -80,6 +80,31 @@ DH uint32_t clamp255(int32_t v) { return (uint32_t)clampi(v, 0, 255); }
 DH uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
 DH uint32_t bswap32(uint32_t v) { return perm(0u, v, 0x00010203u); }
 
+// ---- two signed 16-bit lanes per VGPR (v_pk_add_u16 / v_pk_sub_u16 / v_pk_ashrrev_i16) --------
+// pack16(lo, hi) = lo[15:0] | hi[15:0] << 16 (one v_perm_b32)
+DH uint32_t pack16(uint32_t lo, uint32_t hi) { return perm(hi, lo, 0x05040100u); }
+#if defined(__HIPCC__)
+typedef int16_t pk_i16 __attribute__((ext_vector_type(2)));
+DH pk_i16 to_pk_i16(uint32_t v) { pk_i16 r; __builtin_memcpy(&r, &v, 4); return r; }
+DH uint32_t of_pk_i16(pk_i16 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+DH uint32_t pk_add16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) + to_pk_i16(b)); }
+DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) - to_pk_i16(b)); }
+DH uint32_t pk_ashr16(uint32_t a, int s) { return of_pk_i16(to_pk_i16(a) >> (int16_t)s); }
+// both signed 16-bit lanes clamped to 0..255: lane 0 -> byte 0, lane 1 -> byte 1.  Only bytes 0
+// and 1 of the result may be used (callers gather them with v_perm_b32).
+DH uint32_t sat_u8_pk16(uint32_t a) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a)); return r; }
+#else
+DH uint32_t pk_add16(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
+DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }
+DH uint32_t pk_ashr16(uint32_t a, int s) {
+	return ((uint32_t)((int32_t)(int16_t)(a & 0xFFFFu) >> s) & 0xFFFFu) | ((uint32_t)((int32_t)(int16_t)(a >> 16) >> s) << 16);
+}
+DH uint32_t sat_u8_pk16(uint32_t a) {
+	const int32_t lo = (int16_t)(a & 0xFFFFu), hi = (int16_t)(a >> 16);
+	return (uint32_t)clampi(lo, 0, 255) | ((uint32_t)clampi(hi, 0, 255) << 8) | 0xDEAD0000u;	// poison the unspecified half
+}
+#endif
+
 // 4-way select of packed values by a 2-bit selector held as two lane masks
 DH uint32_t select4(uint32_t m_lo, uint32_t m_hi, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
 	return bfi(m_hi, bfi(m_lo, p3, p2), bfi(m_lo, p1, p0));
@@ -101,6 +126,30 @@ DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
 	return __builtin_amdgcn_alignbit(bfi(k0, x_hi, x_mid), bfi(k0, x_mid, x_lo), pos & 31u);
 }
 DH uint32_t extract_bits(const Bits128 &b, uint32_t pos, uint32_t n) { return ubfe(extract32(b, pos), 0, n); }
+
+// ---- per-lane private rows in LDS ------------------------------------------------------------
+// ROWS values of T owned by each lane of a 256-thread workgroup, laid out [row][lane] so that any
+// mix of per-lane row numbers is bank-conflict free.  Used where a decoder must pick one of a few
+// per-block values by a per-lane, per-texel index: a dynamic register index would become a chain
+// of v_bfi/v_cndmask (VALU, the scarce resource of the BPTC kernels), whereas ds_read_b128 with
+// a computed address costs one address op and runs on the otherwise idle LDS pipe.  A lane only
+// ever reads what it wrote itself: no barrier.  TAG keeps distinct tables distinct.
+template <class T, int ROWS, int TAG> struct LaneRows {
+#if defined(__HIPCC__)
+	T *p;
+	DH LaneRows() {
+		__shared__ T mem[ROWS * 256];
+		p = mem + threadIdx.x;
+	}
+	DH void put(int r, const T &v) { p[r * 256] = v; }
+	DH T get(uint32_t r) const { return p[r * 256u]; }
+#else
+	T mem[ROWS];
+	DH LaneRows() {}
+	DH void put(int r, const T &v) { mem[r] = v; }
+	DH T get(uint32_t r) const { return mem[r]; }
+#endif
+};
 #endif  // DETEXHIP_DEVICE_CODE
 
 }  // namespace detexhip

@@ -242,6 +242,29 @@ def test_bc1_tile4x4_variant_matches(torch_cuda, oracle):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3)])
+def test_alternative_decoder_variants_match(name, variant, torch_cuda, oracle, forced_vectors):
+    """the A/B decoder implementations decode identically, forced classes included"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    W, H = 2048, 512
+    n = (W // 4) * (H // 4)
+    forced = forced_vectors[name + "/in"].reshape(-1)
+    data = np.concatenate([forced, ol.stream_u(fmt, n, seed=0xAB + variant)])[:n * fmt.block_bytes]
+    ok_o, want = oracle.linear(fmt, data, W, H)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    binding.set_kernel_variant(variant)
+    try:
+        out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+        torch.cuda.synchronize()
+    finally:
+        binding.set_kernel_variant(0)
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want), _first_diff(got, want, 16 * fmt.pixel_bytes)
+    assert bool(status.item() == 0) == ok_o
+
+
 # ---- (iv) BASELINE.json's full size: 8192x8192 streams against the reference's digests ----------
 HEADLINE = ["BC1", "BC3", "BPTC", "ETC2", "ETC2_EAC", "BPTC_FLOAT"]
 

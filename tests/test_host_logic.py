@@ -96,6 +96,19 @@ def test_device_logic_under_emulation(fmt, emul, oracle, forced_vectors):
     assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
 
 
+@pytest.mark.parametrize("alt,name", [(109, "BPTC_FLOAT"), (110, "BPTC_SIGNED_FLOAT"), (111, "BPTC"), (112, "BPTC")])
+def test_alternative_decoders_under_emulation(alt, name, emul, oracle, forced_vectors):
+    """The A/B decoder implementations behind detexhipSetKernelVariant(3/4) decode identically."""
+    import types
+    fmt = F.BY_NAME[name]
+    blocks = np.concatenate([forced_vectors[name + "/in"], ol.stream_u(fmt, 1 << 14, seed=0xA17 + alt).reshape(-1, fmt.block_bytes)])
+    shim = types.SimpleNamespace(index=alt, block_bytes=fmt.block_bytes, pixel_bytes=fmt.pixel_bytes)
+    for checked in (1, 0):
+        ok_e, out_e = emul(shim, blocks, checked=checked)
+        ok_o, out_o = oracle.blocks(fmt, blocks)
+        assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
+
+
 # ---- sharding -----------------------------------------------------------------------------------------
 def test_shard_arithmetic_tiles_the_texture_exactly():
     for fmt in (F.BY_NAME["BC1"], F.BY_NAME["BPTC_FLOAT"], F.BY_NAME["RGTC1"]):

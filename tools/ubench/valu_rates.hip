@@ -50,6 +50,29 @@ KERNEL(dep1_bfe, "v_bfe_u32 %0, %0, %4, %5\n v_bfe_u32 %0, %0, %5, %4\n v_bfe_u3
 KERNEL(dep2_bfe, "v_bfe_u32 %0, %0, %4, %5\n v_bfe_u32 %1, %1, %5, %4\n v_bfe_u32 %0, %0, %4, %5\n v_bfe_u32 %1, %1, %5, %4")
 KERNEL(dep1_mix, "v_mad_i32_i24 %0, %0, %4, %5\n v_lshrrev_b32 %0, 6, %0\n v_mul_i32_i24 %0, 31, %0\n v_lshrrev_b32 %0, 6, %0")
 KERNEL(dep2_mix, "v_mad_i32_i24 %0, %0, %4, %5\n v_mad_i32_i24 %1, %1, %4, %5\n v_lshrrev_b32 %0, 6, %0\n v_lshrrev_b32 %1, 6, %1")
+// encoding size vs operand count: the same add as VOP2 (4 bytes), VOP3 (8 bytes), VOP2 + 32-bit literal (8 bytes)
+KERNEL(add_e64, "v_add_u32_e64 %0, %0, %4\n v_add_u32_e64 %1, %1, %5\n v_add_u32_e64 %2, %2, %4\n v_add_u32_e64 %3, %3, %5")
+KERNEL(and_literal, "v_and_b32 %0, 0x12345678, %0\n v_and_b32 %1, 0x0f0f0f0f, %1\n v_and_b32 %2, 0x12345678, %2\n v_and_b32 %3, 0x0f0f0f0f, %3")
+KERNEL(and_inline, "v_and_b32 %0, 15, %0\n v_and_b32 %1, 7, %1\n v_and_b32 %2, 15, %2\n v_and_b32 %3, 7, %3")
+KERNEL(and_sgpr, "v_and_b32 %0, s20, %0\n v_and_b32 %1, s21, %1\n v_and_b32 %2, s20, %2\n v_and_b32 %3, s21, %3")
+KERNEL(bfe_inline, "v_bfe_u32 %0, %0, 4, 8\n v_bfe_u32 %1, %1, 3, 9\n v_bfe_u32 %2, %2, 4, 8\n v_bfe_u32 %3, %3, 3, 9")
+KERNEL(bfe_sgpr, "v_bfe_u32 %0, %0, s20, 8\n v_bfe_u32 %1, %1, s21, 9\n v_bfe_u32 %2, %2, s20, 8\n v_bfe_u32 %3, %3, s21, 9")
+KERNEL(perm_sgpr_sel, "v_perm_b32 %0, %0, %4, s20\n v_perm_b32 %1, %1, %5, s21\n v_perm_b32 %2, %2, %4, s20\n v_perm_b32 %3, %3, %5, s21")
+KERNEL(v_mov, "v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %4\n v_mov_b32 %3, %5")
+KERNEL(v_sat_pk, "v_sat_pk_u8_i16 %0, %0\n v_sat_pk_u8_i16 %1, %1\n v_sat_pk_u8_i16 %2, %2\n v_sat_pk_u8_i16 %3, %3")
+KERNEL(v_pk_add_u16, "v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %5\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %5")
+KERNEL(v_pk_ashr, "v_pk_ashrrev_i16 %0, 2, %0 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %1, 2, %1 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %2, 2, %2 op_sel_hi:[0,1]\n v_pk_ashrrev_i16 %3, 2, %3 op_sel_hi:[0,1]")
+KERNEL(v_lshl_add, "v_lshl_add_u32 %0, %0, 2, %4\n v_lshl_add_u32 %1, %1, 3, %5\n v_lshl_add_u32 %2, %2, 2, %4\n v_lshl_add_u32 %3, %3, 3, %5")
+KERNEL(v_add3, "v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %5, %4\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %5, %4")
+KERNEL(v_xor, "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %5\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %5")
+KERNEL(v_sub, "v_sub_u32 %0, %0, %4\n v_sub_u32 %1, %1, %5\n v_sub_u32 %2, %2, %4\n v_sub_u32 %3, %3, %5")
+KERNEL(v_lshlrev, "v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 5, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 5, %3")
+KERNEL(v_min_max, "v_max_i32 %0, %0, %4\n v_min_i32 %1, %1, %5\n v_max_i32 %2, %2, %4\n v_min_i32 %3, %3, %5")
+KERNEL(v_ffbl, "v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3")
+// mixes: do VOP2 and VOP3 overlap, does SALU work ride along for free
+KERNEL(mix_add_bfe, "v_add_u32 %0, %0, %4\n v_bfe_u32 %1, %1, %5, %4\n v_add_u32 %2, %2, %4\n v_bfe_u32 %3, %3, %5, %4")
+KERNEL(mix_valu_salu, "v_bfe_u32 %0, %0, %4, %5\n s_add_u32 s20, s20, 1\n v_bfe_u32 %1, %1, %5, %4\n s_and_b32 s21, s21, s20\n v_bfe_u32 %2, %2, %4, %5\n s_add_u32 s20, s20, 3\n v_bfe_u32 %3, %3, %5, %4\n s_lshl_b32 s21, s21, 1")
+KERNEL(mix_add_salu, "v_add_u32 %0, %0, %4\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, %5\n s_and_b32 s21, s21, s20\n v_add_u32 %2, %2, %4\n s_add_u32 s20, s20, 3\n v_add_u32 %3, %3, %5\n s_lshl_b32 s21, s21, 1")
 KERNEL(v_lshrrev_b64, "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %5\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %5")
 
 struct Entry { const char *name; void (*fn)(uint32_t *, uint32_t, int); };
@@ -57,7 +80,9 @@ struct Entry { const char *name; void (*fn)(uint32_t *, uint32_t, int); };
 int main() {
 	Entry table[] = { E(v_add_u32), E(v_mul_u32_u24), E(v_mul_i32_i24), E(v_mad_i32_i24), E(v_mad_u32_u24), E(v_mul_lo_u32), E(v_mul_hi_u32),
 		E(v_bfe_u32), E(v_bfi_b32), E(v_perm_b32), E(v_alignbit_b32), E(v_lshl_or_b32), E(v_and_or_b32), E(v_med3_i32), E(v_lshrrev_b32),
-		E(v_pk_mad_u16), E(v_cndmask_b32), E(v_cmp_cnd), E(v_bfrev_b32), E(cnd_sgpr_mask), E(cnd_add_1to1), E(cnd_bfe_1to1), E(cnd_1_in_4), E(cmp_then_3cnd), E(cnd_e64_vcc), E(bfe_i32_mask), E(dep1_add), E(dep2_add), E(dep1_bfe), E(dep2_bfe), E(dep1_mix), E(dep2_mix) };
+		E(v_pk_mad_u16), E(v_cndmask_b32), E(v_cmp_cnd), E(v_bfrev_b32), E(cnd_sgpr_mask), E(cnd_add_1to1), E(cnd_bfe_1to1), E(cnd_1_in_4), E(cmp_then_3cnd), E(cnd_e64_vcc), E(bfe_i32_mask), E(dep1_add), E(dep2_add), E(dep1_bfe), E(dep2_bfe), E(dep1_mix), E(dep2_mix),
+		E(add_e64), E(and_literal), E(and_inline), E(and_sgpr), E(bfe_inline), E(bfe_sgpr), E(perm_sgpr_sel), E(v_mov), E(v_sat_pk), E(v_pk_add_u16),
+		E(v_pk_ashr), E(v_lshl_add), E(v_add3), E(v_xor), E(v_sub), E(v_lshlrev), E(v_min_max), E(v_ffbl), E(mix_add_bfe), E(mix_valu_salu), E(mix_add_salu) };
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount, blocks = cus * 8, iters = 512;	// 8 blocks x 4 waves = 32 waves/CU = 8 per SIMD
 	const double clk = prop.clockRate * 1e3;
