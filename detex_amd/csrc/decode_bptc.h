@@ -41,6 +41,28 @@ __constant__ uint32_t kBc7ModeDesc[8] = {
 	bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0),
 };
 
+// workgroup copies in LDS (dev_common.h: prepare_tables).  anchor_p1[i] = kAnchorWords[i] | kPartition1Bit[i] << 16
+struct BptcTables { uint32_t part2[128]; uint32_t anchor_p1[64]; uint32_t desc[8]; };
+#if defined(__HIPCC__)
+DH BptcTables &bptc_tables() { __shared__ BptcTables t; return t; }
+DH void bptc_prepare() {
+	BptcTables &t = bptc_tables();
+	const uint32_t k = threadIdx.x;
+	if (k < 128u) t.part2[k] = kPartition2Bit[k];
+	else if (k < 192u) t.anchor_p1[k - 128u] = (uint32_t)kAnchorWords[k - 128u] | ((uint32_t)kPartition1Bit[k - 128u] << 16);
+	else if (k < 200u) t.desc[k - 192u] = kBc7ModeDesc[k - 192u];
+	__syncthreads();
+}
+DH uint32_t bptc_part2(uint32_t i) { return bptc_tables().part2[i]; }
+DH uint32_t bptc_anchor_p1(uint32_t i) { return bptc_tables().anchor_p1[i]; }
+DH uint32_t bptc_desc(uint32_t m) { return bptc_tables().desc[m]; }
+#else
+DH void bptc_prepare() {}
+DH uint32_t bptc_part2(uint32_t i) { return kPartition2Bit[i]; }
+DH uint32_t bptc_anchor_p1(uint32_t i) { return (uint32_t)kAnchorWords[i] | ((uint32_t)kPartition1Bit[i] << 16); }
+DH uint32_t bptc_desc(uint32_t m) { return kBc7ModeDesc[m]; }
+#endif
+
 // weight(index) for a per-lane index width: (64*i + d/2) / d as multiply-shift (dev_common.h)
 struct WeightParams { uint32_t half, magic; };
 DH WeightParams weight_params(uint32_t bits) {
@@ -94,6 +116,7 @@ DH WeightMad weight_mad(uint32_t bits) {
 //   2  as 1, and block fields are fetched from an LDS copy of the block (two dwords + v_alignbit)
 template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
+	static DH void prepare() { bptc_prepare(); }
 
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		const uint32_t low = blk.x & 0xFFu;
@@ -108,7 +131,7 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 			bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0), bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0), bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
 			bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0), bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3), bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
 			bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0), bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0) };
-		const uint32_t desc = FIXED_MODE >= 0 ? kDesc[FIXED_MODE >= 0 ? FIXED_MODE : 0] : kBc7ModeDesc[mode];
+		const uint32_t desc = FIXED_MODE >= 0 ? kDesc[FIXED_MODE >= 0 ? FIXED_MODE : 0] : bptc_desc(mode);
 		const uint32_t ns = desc & 3u, pb = ubfe(desc, 2, 3), rb = ubfe(desc, 5, 2), isb = ubfe(desc, 7, 1);
 		const uint32_t cb = ubfe(desc, 8, 3), ab = ubfe(desc, 11, 4), epb = ubfe(desc, 15, 1), spb = ubfe(desc, 16, 1);
 		const uint32_t ib = ubfe(desc, 17, 3), ib2 = ubfe(desc, 20, 2);
@@ -167,8 +190,8 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		}
 
 		// partition + anchors (:391-400)
-		const uint32_t pword = ns == 1u ? 0u : kPartition2Bit[part + (ns == 3u ? 64u : 0u)];
-		const uint32_t an = kAnchorWords[part];
+		const uint32_t pword = ns == 1u ? 0u : bptc_part2(part + (ns == 3u ? 64u : 0u));
+		const uint32_t an = bptc_anchor_p1(part);
 		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
 		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
 		// gather the high bytes of the four 16-bit sums; rotation swaps A with R/G/B (:497-508)

@@ -158,8 +158,22 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 	bc6h_derive(7).w, bc6h_derive(8).w, bc6h_derive(9).w, bc6h_derive(10).w, bc6h_derive(11).w, bc6h_derive(12).w, bc6h_derive(13).w,
 };
 
+// workgroup copy of the mode words in LDS (dev_common.h: prepare_tables); the partition / anchor words come
+// from the BPTC tables (decode_bptc.h)
+#if defined(__HIPCC__)
+DH Bc6hModeWords *bc6h_mode_words_lds() { __shared__ Bc6hModeWords t[14]; return t; }
+DH void bc6h_prepare() {
+	if (threadIdx.x >= 200u && threadIdx.x < 214u) bc6h_mode_words_lds()[threadIdx.x - 200u] = kBc6hModeWords[threadIdx.x - 200u];
+	bptc_prepare();		// ends in the workgroup barrier
+}
+DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_mode_words_lds()[mode]; }
+#else
+DH void bc6h_prepare() {}
+DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return kBc6hModeWords[mode]; }
+#endif
+
 DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t (&ep)[3][4]) {
-	const Bc6hModeWords mw = kBc6hModeWords[mode];
+	const Bc6hModeWords mw = bc6h_mode_words(mode);
 	const uint32_t w0 = mw.a & 15u, rw = ubfe(mw.a, 4, 4), gw = ubfe(mw.a, 8, 4), bw = ubfe(mw.a, 12, 4);
 	const bool transformed = (mw.a >> 21) & 1u, one = mode >= 10u;
 	// main fields at their canonical positions, per-lane widths
@@ -215,6 +229,7 @@ DH int32_t bc6h_unquantize_signed(int32_t x, uint32_t epb) {
 // default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8;
+	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t, uint32_t (&d)[32]) {
@@ -263,8 +278,9 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		}
 		// partition (5 bits at block bit 77), anchor, index stream (:535-564)
 		const uint32_t part = two ? ubfe(blk.z, 13, 5) : 0u;
-		const uint32_t pmask = two ? (uint32_t)kPartition1Bit[part] : 0u;
-		const uint32_t amask = 1u | (two ? (1u << (kAnchorWords[part] & 0xFu)) : 0u);
+		const uint32_t an = bptc_anchor_p1(part);		// anchor nibbles | one-bit partition << 16
+		const uint32_t pmask = two ? (an >> 16) : 0u;
+		const uint32_t amask = 1u | (two ? (1u << (an & 0xFu)) : 0u);
 		const uint32_t ibits = two ? 3u : 4u;
 		// Index stream, LSB-first, read through two 32-bit windows: texels 0-7 consume 8*ibits - (anchors among
 		// them) <= 31 bits (texel 0 is always an anchor), texels 8-15 start where they ended, and that second window

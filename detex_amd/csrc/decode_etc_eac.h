@@ -33,6 +33,19 @@ __constant__ uint16_t kEacMagnitudes[16] = {
 	0xA862, 0xA852, 0xA842, 0xA752, 0xA743, 0xA321, 0x9864, 0x9753,
 };
 
+// workgroup copy of the table in LDS (dev_common.h: prepare_tables)
+#if defined(__HIPCC__)
+DH uint16_t *eac_rows_lds() { __shared__ uint16_t rows[16]; return rows; }
+DH void eac_prepare() {
+	if (threadIdx.x < 16u) eac_rows_lds()[threadIdx.x] = kEacMagnitudes[threadIdx.x];
+	__syncthreads();
+}
+DH uint32_t eac_row(uint32_t t) { return eac_rows_lds()[t]; }
+#else
+DH void eac_prepare() {}
+DH uint32_t eac_row(uint32_t t) { return kEacMagnitudes[t]; }
+#endif
+
 DH uint32_t rep4(uint32_t v) { return v | (v << 4); }
 
 // Arithmetic of this file runs two signed 16-bit lanes per VGPR (dev_common.h: pk_add16 / pk_sub16 /
@@ -217,7 +230,7 @@ DH EacWord eac_word(uint32_t w0, uint32_t w1) {
 	EacWord e;
 	e.base = hi >> 24;
 	e.mult = (hi >> 20) & 0xFu;
-	e.row = kEacMagnitudes[(hi >> 16) & 0xFu];
+	e.row = eac_row((hi >> 16) & 0xFu);
 	e.sel_a = ((hi & 0xFFFFu) << 8) | (lo >> 24);	// texels 0-7, texel 0 in bits 23:21
 	e.sel_b = lo & 0xFFFFFFu;			// texels 8-15
 	return e;
@@ -300,6 +313,7 @@ struct DecETC2Punchthrough {
 	}
 };
 struct DecETC2EAC {
+	static DH void prepare() { eac_prepare(); }
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
 	// decompress-eac.c:54-86: colour = ETC2 on bytes 8-15, alpha = EAC on bytes 0-7
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
@@ -310,18 +324,21 @@ struct DecETC2EAC {
 	}
 };
 struct DecEACR11 {
+	static DH void prepare() { eac_prepare(); }
 	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return eac11_channel<false>(blk.x, blk.y, d);
 	}
 };
 struct DecEACSignedR11 {
+	static DH void prepare() { eac_prepare(); }
 	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return eac11_channel<true>(blk.x, blk.y, d);
 	}
 };
 template <bool SIGNED> struct DecEACRG11T {
+	static DH void prepare() { eac_prepare(); }
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
 	// decompress-eac.c:144-157, 217-231: texel = R16 | G16 << 16
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {

@@ -71,8 +71,19 @@ DH uint32_t opaque(uint32_t m) { return m; }
 DH uint32_t bit_to_mask(uint32_t v, uint32_t bit) { return opaque((uint32_t)__builtin_amdgcn_sbfe((int32_t)v, bit, 1u)); }
 // all-ones if c, else 0: one v_cndmask to build the mask, then any number of v_bfi_b32 selects
 DH uint32_t cond_to_mask(bool c) { return opaque(c ? 0xFFFFFFFFu : 0u); }
-// (a & m) | (b & ~m)  -> v_bfi_b32
+// (a & m) | (b & ~m).  Written as gfx950's v_bitop3_b32 (truth table 0xCA for m, a, b): it issues in 2.5
+// cycles per wave64 like the plain VOP2 logic ops, against 4.5 for v_bfi_b32 / v_and_or_b32 / v_perm_b32
+// (tools/ubench/valu_rates.hip; profiles/r01/valu_rates.txt).
+#if defined(__HIPCC__)
+DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+// (a & b) | c and a | b | c through the same instruction
+DH uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
+DH uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
+#else
 DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+DH uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+DH uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
+#endif
 // byte permute: result byte i = byte sel[i] of the 8-byte pool {s0 (4..7), s1 (0..3)}; 0x0C -> 0x00
 DH uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 DH int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
@@ -126,6 +137,16 @@ DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
 	return __builtin_amdgcn_alignbit(bfi(k0, x_hi, x_mid), bfi(k0, x_mid, x_lo), pos & 31u);
 }
 DH uint32_t extract_bits(const Bits128 &b, uint32_t pos, uint32_t n) { return ubfe(extract32(b, pos), 0, n); }
+
+// ---- workgroup-shared lookup tables in LDS ---------------------------------------------------------
+// A decoder that needs format tables declares `static DH void prepare()`: every kernel calls
+// prepare_tables<Dec>() with all 256 threads before anything else (it ends in a workgroup barrier),
+// which copies the tables from __constant__ memory into LDS once per workgroup.  A table lookup by a
+// per-lane index is then one ds_read instead of a dependent global load queued behind the kernel's own
+// streaming stores (the BPTC decoders chain three such lookups in front of all their arithmetic).
+template <class D> DH auto call_prepare(int) -> decltype(D::prepare(), void()) { D::prepare(); }
+template <class D> DH void call_prepare(long) {}
+template <class D> DH void prepare_tables() { call_prepare<D>(0); }
 
 // ---- per-lane private rows in LDS ------------------------------------------------------------
 // ROWS values of T owned by each lane of a 256-thread workgroup, laid out [row][lane] so that any

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ bl
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
 		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ bl
 		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
 		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];

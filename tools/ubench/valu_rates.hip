@@ -73,6 +73,21 @@ KERNEL(v_ffbl, "v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ff
 KERNEL(mix_add_bfe, "v_add_u32 %0, %0, %4\n v_bfe_u32 %1, %1, %5, %4\n v_add_u32 %2, %2, %4\n v_bfe_u32 %3, %3, %5, %4")
 KERNEL(mix_valu_salu, "v_bfe_u32 %0, %0, %4, %5\n s_add_u32 s20, s20, 1\n v_bfe_u32 %1, %1, %5, %4\n s_and_b32 s21, s21, s20\n v_bfe_u32 %2, %2, %4, %5\n s_add_u32 s20, s20, 3\n v_bfe_u32 %3, %3, %5, %4\n s_lshl_b32 s21, s21, 1")
 KERNEL(mix_add_salu, "v_add_u32 %0, %0, %4\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, %5\n s_and_b32 s21, s21, s20\n v_add_u32 %2, %2, %4\n s_add_u32 s20, s20, 3\n v_add_u32 %3, %3, %5\n s_lshl_b32 s21, s21, 1")
+KERNEL(lshl_vgpr, "v_lshlrev_b32 %0, %4, %0\n v_lshlrev_b32 %1, %5, %1\n v_lshlrev_b32 %2, %4, %2\n v_lshlrev_b32 %3, %5, %3")
+KERNEL(lshr_inline, "v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 5, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 5, %3")
+KERNEL(ashr_inline, "v_ashrrev_i32 %0, 3, %0\n v_ashrrev_i32 %1, 5, %1\n v_ashrrev_i32 %2, 3, %2\n v_ashrrev_i32 %3, 5, %3")
+KERNEL(v_or, "v_or_b32 %0, %0, %4\n v_or_b32 %1, %1, %5\n v_or_b32 %2, %2, %4\n v_or_b32 %3, %3, %5")
+KERNEL(v_not, "v_not_b32 %0, %0\n v_not_b32 %1, %1\n v_not_b32 %2, %2\n v_not_b32 %3, %3")
+KERNEL(v_bitop3, "v_bitop3_b32 %0, %0, %4, %5 bitop3:0xe0\n v_bitop3_b32 %1, %1, %5, %4 bitop3:0xe0\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0xe0\n v_bitop3_b32 %3, %3, %5, %4 bitop3:0xe0")
+KERNEL(v_bcnt, "v_bcnt_u32_b32 %0, %0, %4\n v_bcnt_u32_b32 %1, %1, %5\n v_bcnt_u32_b32 %2, %2, %4\n v_bcnt_u32_b32 %3, %3, %5")
+KERNEL(and_sdwa, "v_and_b32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %1, %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %3, %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+KERNEL(add_sdwa, "v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %1, %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %3, %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+KERNEL(mov_sdwa, "v_mov_b32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_mov_b32_sdwa %1, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_mov_b32_sdwa %2, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_mov_b32_sdwa %3, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0")
+KERNEL(add_lit, "v_add_u32 %0, 0x12345, %0\n v_add_u32 %1, 0x54321, %1\n v_add_u32 %2, 0x12345, %2\n v_add_u32 %3, 0x54321, %3")
+KERNEL(max_u32, "v_max_u32 %0, %0, %4\n v_max_u32 %1, %1, %5\n v_max_u32 %2, %2, %4\n v_max_u32 %3, %3, %5")
+KERNEL(cmp_only, "v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 s[20:21], %1, %5\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 s[20:21], %3, %5")
+KERNEL(pk_mul_lo, "v_pk_mul_lo_u16 %0, %0, %4\n v_pk_mul_lo_u16 %1, %1, %5\n v_pk_mul_lo_u16 %2, %2, %4\n v_pk_mul_lo_u16 %3, %3, %5")
+KERNEL(pk_min_max, "v_pk_max_i16 %0, %0, %4\n v_pk_min_i16 %1, %1, %5\n v_pk_max_i16 %2, %2, %4\n v_pk_min_i16 %3, %3, %5")
 KERNEL(v_lshrrev_b64, "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %5\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %5")
 
 struct Entry { const char *name; void (*fn)(uint32_t *, uint32_t, int); };
@@ -82,7 +97,9 @@ int main() {
 		E(v_bfe_u32), E(v_bfi_b32), E(v_perm_b32), E(v_alignbit_b32), E(v_lshl_or_b32), E(v_and_or_b32), E(v_med3_i32), E(v_lshrrev_b32),
 		E(v_pk_mad_u16), E(v_cndmask_b32), E(v_cmp_cnd), E(v_bfrev_b32), E(cnd_sgpr_mask), E(cnd_add_1to1), E(cnd_bfe_1to1), E(cnd_1_in_4), E(cmp_then_3cnd), E(cnd_e64_vcc), E(bfe_i32_mask), E(dep1_add), E(dep2_add), E(dep1_bfe), E(dep2_bfe), E(dep1_mix), E(dep2_mix),
 		E(add_e64), E(and_literal), E(and_inline), E(and_sgpr), E(bfe_inline), E(bfe_sgpr), E(perm_sgpr_sel), E(v_mov), E(v_sat_pk), E(v_pk_add_u16),
-		E(v_pk_ashr), E(v_lshl_add), E(v_add3), E(v_xor), E(v_sub), E(v_lshlrev), E(v_min_max), E(v_ffbl), E(mix_add_bfe), E(mix_valu_salu), E(mix_add_salu) };
+		E(v_pk_ashr), E(v_lshl_add), E(v_add3), E(v_xor), E(v_sub), E(v_lshlrev), E(v_min_max), E(v_ffbl), E(mix_add_bfe), E(mix_valu_salu), E(mix_add_salu),
+		E(lshl_vgpr), E(lshr_inline), E(ashr_inline), E(v_or), E(v_not), E(v_bitop3), E(v_bcnt), E(and_sdwa), E(add_sdwa), E(mov_sdwa), E(add_lit), E(max_u32),
+		E(cmp_only), E(pk_mul_lo), E(pk_min_max) };
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount, blocks = cus * 8, iters = 512;	// 8 blocks x 4 waves = 32 waves/CU = 8 per SIMD
 	const double clk = prop.clockRate * 1e3;
