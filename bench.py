@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (include/detexhip.h)")
     ap.add_argument("--stream", default="U", choices=["U", "M"])
+    ap.add_argument("--layout", default="linear", choices=["linear", "tiled"],
+                    help="linear = detexDecompressTextureLinear (headline); tiled = detexDecompressTextureTiled (block-major output)")
     ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--gather", action="store_true", help="also time the optional whole-image all-gather (N>1)")
@@ -162,7 +164,10 @@ def main():
         pf, tpx = target_of(fmt)
         d_out = torch.empty(W * H * tpx, dtype=torch.uint8, device="cuda")
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        step = lambda: binding.decompress_linear_device(fmt, d_blocks, W, H, out=d_out, status=status, pixel_format=pf)
+        if args.layout == "tiled":
+            step = lambda: binding.decompress_tiled_device(fmt, d_blocks, W // 4, H // 4, out=d_out, status=status, pixel_format=pf)
+        else:
+            step = lambda: binding.decompress_linear_device(fmt, d_blocks, W, H, out=d_out, status=status, pixel_format=pf)
         for _ in range(warmup):
             step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -216,7 +221,7 @@ def main():
         "config": {"workload": "%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, "
                                "sharded by block rows: one %d-row band per GPU" % (fmt.name, F.target_name(fmt), W, H, args.stream, H),
                    "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": blocks,
-                   "kernel": binding.kernel_name(fmt), "variant": args.variant, "target_pixel_format": "0x%04X" % pf},
+                   "kernel": binding.kernel_name(fmt) if args.layout == "linear" else "decode_blocks", "layout": args.layout, "variant": args.variant, "target_pixel_format": "0x%04X" % pf},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
@@ -239,7 +244,10 @@ def main():
         # bit-exactness of what was just timed, against the CPU checker on a bounded sample (first 64 block rows)
         rows = 64
         orc = ol.Oracle()
-        ok_o, want = orc.linear_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W, rows * 4, pf)
+        if args.layout == "tiled":
+            ok_o, want = orc.tiled_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W // 4, rows, pf)
+        else:
+            ok_o, want = orc.linear_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W, rows * 4, pf)
         got = d_out[:want.size].cpu().numpy()
         result["verified_bit_exact_rows"] = rows * 4 if np.array_equal(got, want) else 0
         if not np.array_equal(got, want):
@@ -247,6 +255,8 @@ def main():
             result["value"] = 0.0
         # host-pointer drop-in tier (PCIe-inclusive; never `value`)
         try:
+            if args.layout != "linear":
+                raise RuntimeError("host tier is timed for the linear layout only")
             api = ol.DetexAPI(binding.LIB_PATH)
             host_out = np.empty(W * H * tpx, np.uint8)
             api.linear(fmt, data, W, H, out=host_out, pixel_format=pf)

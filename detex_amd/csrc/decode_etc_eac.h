@@ -246,12 +246,13 @@ DH int32_t eac_modifier(uint32_t row, int s) {
 // multiplier 0 allowed (A-8).  Builds the 8-entry alpha table once, then one v_perm per texel.
 DH void eac_alpha_overlay(uint32_t w0, uint32_t w1, uint32_t (&d)[16]) {
 	const EacWord e = eac_word(w0, w1);
-	uint32_t lo = 0, hi = 0;
-#pragma unroll
-	for (int s = 0; s < 4; s++) {
-		lo |= clamp255((int32_t)e.base + eac_modifier(e.row, s) * (int32_t)e.mult) << (8 * s);
-		hi |= clamp255((int32_t)e.base + eac_modifier(e.row, s + 4) * (int32_t)e.mult) << (8 * s);
-	}
+	// the eight table values base - m*mult (selectors 0-3) and base + (m-1)*mult (4-7), two per VGPR in signed
+	// 16-bit lanes (|m*mult| <= 225), clamped by the saturating pack
+	const uint32_t m01 = (e.row & 0xFu) | ((e.row << 12) & 0xF0000u), m23 = ((e.row >> 8) & 0xFu) | ((e.row << 4) & 0xF0000u);
+	const uint32_t mult2 = DETEX_UMUL24(e.mult, 0x10001u), base2 = DETEX_UMUL24(e.base, 0x10001u);
+	const uint32_t mm01 = pk_mul16(m01, mult2), mm23 = pk_mul16(m23, mult2), bm = pk_sub16(base2, mult2);
+	const uint32_t lo = perm(sat_u8_pk16(pk_sub16(base2, mm23)), sat_u8_pk16(pk_sub16(base2, mm01)), 0x05040100u);
+	const uint32_t hi = perm(sat_u8_pk16(pk_add16(bm, mm23)), sat_u8_pk16(pk_add16(bm, mm01)), 0x05040100u);
 #pragma unroll
 	for (int p = 0; p < 16; p++) {
 		const int idx = (p & 3) * 4 + (p >> 2);

@@ -140,29 +140,41 @@ DH void rgtc_channel_u8(uint32_t w0, uint32_t w1, uint32_t (&rows)[4]) {
 		rows[r] = perm(hi, lo, spread3to8(ubfe(r < 2 ? c.a : c.b, 12 * (r & 1), 12)));
 }
 
-// one signed RGTC channel -> eight dwords of two 16-bit texels each (decompress-rgtc.c:84-130)
+// one signed RGTC channel -> eight dwords of two 16-bit texels each (decompress-rgtc.c:84-130).
+// Every quantity is kept biased so the arithmetic stays unsigned: a ramp value q in [-127,127] is carried as
+// n = q + 127, the reference's truncating /7 and /5 (detex.h:966-982) become floor divisions of
+// x + 128*d + (x < 0 ? d-1 : 0), and the 16-bit map (v+127)*65535/254 - 32768 is
+// (n*258 + floor(3n/254)) ^ 0x8000 with floor(3n/254) = (n*387 + 6) >> 15 on 0..254 (all three identities are
+// checked exhaustively in tests/test_host_logic.py).
+DH uint32_t rgtc_biased_to_u16(uint32_t n) { return DETEX_UMUL24(n, 258u) + ((DETEX_UMUL24(n, 387u) + 6u) >> 15); }
 DH bool rgtc_channel_s16(uint32_t w0, uint32_t w1, uint32_t (&pairs)[8]) {
-	int32_t e0 = (int32_t)(int8_t)(w0 & 0xFFu), e1 = (int32_t)(int8_t)((w0 >> 8) & 0xFFu);
+	int32_t e0 = sbfe(w0, 0, 8), e1 = sbfe(w0, 8, 8);
 	const bool valid = !(e0 == -127 && e1 == -128);		// :90-92
 	e0 = max(e0, -127);
 	e1 = max(e1, -127);
-	const bool seven = e0 > e1;
-	uint32_t v[8];						// mapped 16-bit values
-	v[0] = rgtc_signed_to_16(e0);
-	v[1] = rgtc_signed_to_16(e1);
+	const uint32_t seven = cond_to_mask(e0 > e1);
+	const int32_t step = e1 - e0;
+	uint32_t w[8];						// the eight ramp entries as unsigned 16-bit (sign bit still flipped)
+	w[0] = rgtc_biased_to_u16((uint32_t)(e0 + 127));
+	w[1] = rgtc_biased_to_u16((uint32_t)(e1 + 127));
 #pragma unroll
 	for (int k = 1; k <= 6; k++) {
-		const int32_t q7 = div7_s((7 - k) * e0 + k * e1);
-		const int32_t q5 = k <= 4 ? div5_s((5 - k) * e0 + k * e1) : (k == 5 ? -127 : 127);
-		v[1 + k] = rgtc_signed_to_16(seven ? q7 : q5);
+		const int32_t x7 = 7 * e0 + k * step;		// (7-k)*e0 + k*e1
+		const uint32_t u7 = div7_u((uint32_t)(x7 + 896 + ((x7 >> 31) & 6)));	// trunc(x7/7) + 128
+		uint32_t u5;
+		if (k <= 4) {
+			const int32_t x5 = 5 * e0 + k * step;
+			u5 = div5_u((uint32_t)(x5 + 640 + ((x5 >> 31) & 4)));		// trunc(x5/5) + 128
+		} else {
+			u5 = k == 5 ? 1u : 255u;					// -127 and 127
+		}
+		w[1 + k] = rgtc_biased_to_u16(bfi(seven, u7, u5) - 1u);
 	}
-	// split the eight 16-bit entries into a low-byte and a high-byte table for v_perm
-	uint32_t lo_l = 0, lo_h = 0, hi_l = 0, hi_h = 0;
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		lo_l |= (v[k] & 0xFFu) << (8 * k);      hi_l |= (v[k] >> 8) << (8 * k);
-		lo_h |= (v[4 + k] & 0xFFu) << (8 * k);  hi_h |= (v[4 + k] >> 8) << (8 * k);
-	}
+	// low-byte and high-byte tables of the eight entries for v_perm lookups
+	const uint32_t p01 = perm(w[1], w[0], 0x05010400u), p23 = perm(w[3], w[2], 0x05010400u);	// {lo a, lo b, hi a, hi b}
+	const uint32_t p45 = perm(w[5], w[4], 0x05010400u), p67 = perm(w[7], w[6], 0x05010400u);
+	const uint32_t lo_l = perm(p23, p01, 0x05040100u), lo_h = perm(p67, p45, 0x05040100u);
+	const uint32_t hi_l = perm(p23, p01, 0x07060302u) ^ 0x80808080u, hi_h = perm(p67, p45, 0x07060302u) ^ 0x80808080u;
 	const Codes48 c = codes48_from_le(w0, w1);
 #pragma unroll
 	for (int r = 0; r < 4; r++) {

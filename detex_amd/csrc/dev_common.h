@@ -101,6 +101,7 @@ DH uint32_t of_pk_i16(pk_i16 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); retur
 DH uint32_t pk_add16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) + to_pk_i16(b)); }
 DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) - to_pk_i16(b)); }
 DH uint32_t pk_ashr16(uint32_t a, int s) { return of_pk_i16(to_pk_i16(a) >> (int16_t)s); }
+DH uint32_t pk_mul16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) * to_pk_i16(b)); }
 // both signed 16-bit lanes clamped to 0..255: lane 0 -> byte 0, lane 1 -> byte 1.  Only bytes 0
 // and 1 of the result may be used (callers gather them with v_perm_b32).
 DH uint32_t sat_u8_pk16(uint32_t a) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a)); return r; }
@@ -110,6 +111,7 @@ DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a
 DH uint32_t pk_ashr16(uint32_t a, int s) {
 	return ((uint32_t)((int32_t)(int16_t)(a & 0xFFFFu) >> s) & 0xFFFFu) | ((uint32_t)((int32_t)(int16_t)(a >> 16) >> s) << 16);
 }
+DH uint32_t pk_mul16(uint32_t a, uint32_t b) { return ((a * b) & 0xFFFFu) | (((a >> 16) * (b >> 16)) << 16); }
 DH uint32_t sat_u8_pk16(uint32_t a) {
 	const int32_t lo = (int16_t)(a & 0xFFFFu), hi = (int16_t)(a >> 16);
 	return (uint32_t)clampi(lo, 0, 255) | ((uint32_t)clampi(hi, 0, 255) << 8) | 0xDEAD0000u;	// poison the unspecified half

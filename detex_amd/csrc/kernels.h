@@ -227,20 +227,51 @@ template <class Dec, int EPI, bool CHECKED>
 __global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
 		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
-	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;	// = 16-byte vectors per decoded block
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_blocks) return;
-	uint32_t o[4 * ROW];
-	const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
-	uint32_t *dst = reinterpret_cast<uint32_t *>(pixels + (uint64_t)i * (16u * ROW));
-	if constexpr ((4 * ROW) % 4 == 0) {
-		typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	const bool live = i < n_blocks;
+	if constexpr (ROW == 1) {
+		// 16 bytes per block: the wave's output is already one contiguous 1 KiB run per store instruction
+		if (!live) return;
+		uint32_t o[4];
+		const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
+		__builtin_nontemporal_store(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
+		if (ok_out) ok_out[i] = ok ? 1 : 0;
+		raise_status(!ok, status);
+	} else {
+		// A lane's block is ROW vectors = 16*ROW contiguous bytes, so a direct store instruction would write
+		// 16 bytes out of every 16*ROW: partial lines, measured 91 us against 43 us for the linear layout on
+		// BC1 8192^2.  The wave's blocks are contiguous in the output, so they are staged in LDS in output
+		// order and written back as ROW instructions of one contiguous 1 KiB run each.  Lanes past the end
+		// of the stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
+		__shared__ v4 stage[4][64 * ROW];
+		v4 *slab = stage[threadIdx.x >> 6];
+		const uint32_t lane = threadIdx.x & 63u;
+		uint32_t o[4 * ROW];
+		bool ok = true;
+		if (live) {
+			ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
 #pragma unroll
-		for (int k = 0; k < ROW; k++) reinterpret_cast<v4 *>(dst)[k] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+			for (int k = 0; k < ROW; k++) slab[lane * ROW + k] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+		}
+		// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const uint32_t first = i - lane;						// the wave's first block
+		const uint32_t vectors = (first < n_blocks ? min(64u, n_blocks - first) : 0u) * ROW;
+		v4 *out = reinterpret_cast<v4 *>(pixels) + (uint64_t)first * ROW;
+#pragma unroll
+		for (int k = 0; k < ROW; k++) {
+			const uint32_t e = (uint32_t)k * 64u + lane;
+			if (e < vectors) __builtin_nontemporal_store(slab[e], out + e);
+		}
+		if (!live) return;
+		if (ok_out) ok_out[i] = ok ? 1 : 0;
+		raise_status(!ok, status);
 	}
-	if (ok_out) ok_out[i] = ok ? 1 : 0;
-	raise_status(!ok, status);
 }
 
 }  // namespace detexhip

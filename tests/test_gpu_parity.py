@@ -242,6 +242,32 @@ def test_bc1_tile4x4_variant_matches(torch_cuda, oracle):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_blocks_ragged_counts(fmt, torch_cuda, oracle):
+    """block-major kernels with block counts that end inside a wave / a workgroup: the staged row stores
+    must write exactly n*16*px bytes (canary behind the end) and the right blocks"""
+    from detex_amd import binding
+    torch = torch_cuda
+    px = fmt.pixel_bytes
+    for n in (1, 3, 63, 65, 255, 257, 1000 + 37):
+        data = ol.stream_u(fmt, n, seed=0xBEEF + 7 * n + fmt.index)
+        ok_o, want = oracle.blocks(fmt, data.reshape(-1, fmt.block_bytes))
+        canvas = torch.full((n * 16 * px + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        out, ok = binding.decompress_blocks_device(fmt, _dev(torch, data), n, out=canvas)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy()
+        assert np.array_equal(got[:n * 16 * px], want.reshape(-1)), (fmt.name, n)
+        assert (got[n * 16 * px:] == 0xA5).all(), (fmt.name, n, "wrote past the end")
+        assert np.array_equal(ok.cpu().numpy()[:n].astype(bool), ok_o), (fmt.name, n)
+        # the texture-driver form (no per-block flags) of the same count
+        _, want_t = oracle.tiled(fmt, data, n, 1)
+        canvas.fill_(0xA5)
+        binding.decompress_tiled_device(fmt, _dev(torch, data), n, 1, out=canvas)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy()
+        assert np.array_equal(got[:n * 16 * px], want_t.reshape(-1)) and (got[n * 16 * px:] == 0xA5).all(), (fmt.name, n, "tiled")
+
+
 @pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3)])
 def test_alternative_decoder_variants_match(name, variant, torch_cuda, oracle, forced_vectors):
     """the A/B decoder implementations decode identically, forced classes included"""

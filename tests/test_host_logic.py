@@ -59,6 +59,24 @@ extern "C" int check(void) {
 		}
 	for (int v = -127; v <= 127; v++)
 		if (rgtc_signed_to_16(v) != (uint32_t)(uint16_t)(int16_t)((v + 127) * 65535 / 254 - 32768)) return 200;
+	// the biased forms used by the signed RGTC decoder (decode_s3tc_rgtc.h: rgtc_channel_s16)
+	for (uint32_t n = 0; n <= 254; n++) {
+		if (((n * 387u + 6u) >> 15) != 3 * n / 254) return 201;
+		if (((n * 258u + ((n * 387u + 6u) >> 15)) ^ 0x8000u) != rgtc_signed_to_16((int)n - 127)) return 202;
+	}
+	for (int x = -127 * 7; x <= 127 * 7; x++)
+		if ((int)div7_u((uint32_t)(x + 896 + ((x >> 31) & 6))) - 128 != x / 7) return 203;
+	for (int x = -127 * 5; x <= 127 * 5; x++)
+		if ((int)div5_u((uint32_t)(x + 640 + ((x >> 31) & 4))) - 128 != x / 5) return 204;
+	// BPTC index -> weight as one multiply-add: byte 2 of (64*i + d/2) * ceil(65536/d) (decode_bptc.h: weight_mad)
+	{
+		const uint32_t mul[5] = { 0, 0, 1398144u, 599232u, 279680u }, add[5] = { 0, 0, 21846u, 28089u, 30590u };
+		for (uint32_t bits = 2; bits <= 4; bits++)
+			for (uint32_t i = 0; i < (1u << bits); i++) {
+				const uint32_t t = i * mul[bits] + add[bits];
+				if (t >> 24 || ((t >> 16) & 0xFFu) != bptc_weight(i, bits)) return 210 + bits;
+			}
+	}
 	return 0;
 }
 ''')

@@ -14,3 +14,12 @@ d=json.load(open("$OUT/ab_${f}_v$v.json"))
 print("$f v$v launch_us", d["roofline"].get("launch_us"), "frac", d["roofline"]["frac"], "exact", d.get("verified_bit_exact_rows"))
 PY
 done
+# tiled (block-major) layout of the formats named in $TILED
+for f in ${TILED:-}; do
+  timeout 300 python bench.py --no-cpu --format $f --layout tiled --steps 50 --warmup 5 2>>$OUT/ab.err > $OUT/ab_${f}_tiled.json
+  python - <<PY
+import json
+d=json.load(open("$OUT/ab_${f}_tiled.json"))
+print("$f tiled launch_us", d["roofline"].get("launch_us"), "frac", d["roofline"]["frac"], "exact", d.get("verified_bit_exact_rows"))
+PY
+done
