@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "kernels_extra.h"
 #include "variant_tile4x4.h"
+#include "kernels_sorted.h"
 
 using namespace detexhip;
 
@@ -110,6 +111,12 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 			if (g.variant == 4) {	// A/B: BC7 with block fields extracted from registers (no LDS copy of the block)
 				hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px,
 					g.wb, n, g.pitch, g.status);
+				return hipGetLastError();
+			}
+		}
+		if constexpr (ClassSorted<Dec>::kAvailable && Epilogue<EPI, Dec::kPixelBytes>::kRowDwords == 4) {
+			if (g.variant == 5) {	// A/B: mode-sorted waves (kernels_sorted.h) -- measured slower than the all-modes decoder, DESIGN.md section 5
+				hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 				return hipGetLastError();
 			}
 		}
@@ -294,7 +301,7 @@ int current_variant() {
 	if (c.variant < 0) {
 		const char *env = getenv("DETEXHIP_VARIANT");
 		c.variant = env ? atoi(env) : 0;
-		if (c.variant < 0 || c.variant > 4) c.variant = 0;
+		if (c.variant < 0 || c.variant > 5) c.variant = 0;
 	}
 	return c.variant;
 }
@@ -359,7 +366,7 @@ extern "C" int detexhipSetDevice(int device) {
 
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
-extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 4) ? variant : 0; }
+extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 5) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
 
 extern "C" const char *detexhipKernelName(uint32_t texture_format) {
