@@ -273,7 +273,7 @@ def main():
             for kind in (["U", "M"] if f.name in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT") else ["U"]):
                 args.stream = kind
                 args.target = None
-                _, _, _, w_, ms_ = run_format(f, W, H, max(50, args.steps), 10)    # sustained: VALU-bound kernels run ~20 % faster in a 20-launch burst
+                _, _, _, w_, ms_ = run_format(f, W, H, max(200, args.steps), 400)    # steady state: the first ~300 launches of a VALU-heavy kernel ride a power-management transient
                 ab = blocks * (f.block_bytes + 16 * f.pixel_bytes)
                 table["%s/%s" % (f.name, kind)] = {"launch_us": round(ms_ * 1e3, 2), "gpixel_s": round(W * H / (ms_ * 1e-3) / 1e9, 1),
                                                     "achieved_GBps": round(ab / (ms_ * 1e-3) / 1e9, 1),

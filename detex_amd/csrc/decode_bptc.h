@@ -175,18 +175,19 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 #pragma unroll
 		for (int e = 0; e < 6; e++) {
 			const uint32_t off = (uint32_t)e * cb, offa = (uint32_t)e * ab;
-			uint32_t x = ubfe(wr, off, cb) | (ubfe(wg, off, cb) << 8) | (ubfe(wb, off, cb) << 16);
+			// (three-input logic goes through v_bitop3_b32 -- dev_common.h: and_or / or3 -- at 2.5 cycles instead of 4.4)
+			uint32_t x = or3(ubfe(wr, off, cb), ubfe(wg, off, cb) << 8, ubfe(wb, off, cb) << 16);
 			const uint32_t p = ubfe(pw_e, e, 1);
-			x = (x << has_p) | ((0u - p) & 0x010101u);
-			x = ((x << c_up) | ((x >> c_down) & c_keep)) & 0xFFFFFFu;
-			uint32_t a = 0xFFu;					// :176-179; modes with alpha have at most two subsets
+			x = and_or(0u - p, 0x010101u, x << has_p);
+			x = and_or(x >> c_down, c_keep, x << c_up);		// each byte holds cprec bits: nothing crosses a byte
+			uint32_t a = 0xFF000000u;				// :176-179; modes with alpha have at most two subsets
 			if (e < 4) {
 				a = ubfe(wa, offa, ab);
-				a = (a << epb) | (p & epb);
-				a = ((a << a_up) | (a >> a_down)) & 0xFFu;
-				a = mode < 4u ? 0xFFu : a;
+				a = and_or(p, epb, a << epb);
+				a = ((a << a_up) | (a >> a_down)) << 24;	// bits above the byte fall off the top
+				a = mode < 4u ? 0xFF000000u : a;
 			}
-			ep[e] = x | (a << 24);
+			ep[e] = x | a;
 		}
 
 		// partition + anchors (:391-400)
