@@ -11,7 +11,11 @@
 //          row 4*by+r (T = bytes per target pixel)  ->  four (T=8: eight) wave-wide
 //          non-temporal stores, each a single 0.75-2 KiB contiguous run (full 128 B lines,
 //          no partial-line writes, no read-for-ownership)
-//          tiled layout: each lane owns 16*T contiguous bytes
+//          tiled layout: a lane's block is 16*T contiguous bytes and the wave's 64 blocks are
+//          contiguous too, so they are staged in LDS in output order and leave as T/1 wave-wide
+//          1 KiB-run stores as well (decode_blocks)
+//   tables decoders with format tables copy them from __constant__ memory into LDS once per
+//          workgroup (prepare_tables<Dec>() at kernel entry, dev_common.h)
 // Invalid blocks are zero-filled and raise *status (texture.c:125-128 semantics): one relaxed
 // agent-scope load + (only while it still reads 0) one store per wave, never an atomic RMW.
 #pragma once
@@ -103,9 +107,8 @@ DH void raise_status(bool bad, uint32_t *status) {
 }
 
 // block index -> (block row, block column).  Texture widths are almost always powers of two, where
-// this is a shift and a mask on a wave-uniform (kernel-argument) width.  The generic 32-bit division
-// compiles to v_mul_hi_u32 / v_mul_lo_u32, which were measured ~40x slower than ordinary VALU ops
-// on MI355X, so it is kept off the common path.
+// this is a shift and a mask on a wave-uniform (kernel-argument) width; the generic 32-bit division
+// (a ~20-instruction v_mul_hi_u32 sequence) is kept off the common path.
 DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t &bx) {
 	if ((width_in_blocks & (width_in_blocks - 1u)) == 0u) {
 		by = i >> __builtin_ctz(width_in_blocks);

@@ -108,7 +108,10 @@ DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *
  *   0  lane-per-block, 64x1-block wave tiles, non-temporal row stores (default)
  *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 only]
  *   2  as 0 with ordinary (cached) row stores (and no LDS row transpose for 64-bit pixels)
- *   3  as 0, BPTC_FLOAT field scatter as a per-mode switch instead of descriptor words
+ *   3  as 0 with the alternative decoder: BPTC_FLOAT field scatter as a per-mode switch instead of
+ *      descriptor words; BPTC texel stage selecting subset endpoints with v_bfi chains (no LDS rows)
+ *   4  as 0, BPTC block fields extracted from registers instead of an LDS copy of the block
+ *   5  BPTC with mode-sorted waves (workgroup counting sort by mode; measured slower, kept for the record)
  * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);
