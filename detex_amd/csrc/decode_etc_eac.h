@@ -46,7 +46,6 @@ DH void eac_prepare() {}
 DH uint32_t eac_row(uint32_t t) { return kEacMagnitudes[t]; }
 #endif
 
-DH uint32_t rep4(uint32_t v) { return v | (v << 4); }
 
 // Arithmetic of this file runs two signed 16-bit lanes per VGPR (dev_common.h: pk_add16 / pk_sub16 /
 // pk_ashr16 / sat_u8_pk16): a colour is held as RB = (R, B) lanes plus G, where the G's of two

@@ -1,11 +1,13 @@
 // dev_common.h -- device-side helpers shared by the gfx950 block decoders.
 //
 // Everything here is integer bit manipulation mapped 1:1 onto CDNA4 VALU ops
-// (v_bfe_u32/i32, v_bfi_b32, v_perm_b32, v_med3_i32, v_mul_u32_u24): the decode path has no
-// floating point and no MFMA work.  The exact-division helpers are
-// DETEX_HD so that tests/test_intmath.py can compile them for the host and prove them
-// exhaustively equal to C integer division on the domains the reference's LUTs cover
-// (division-tables.c: 0..767 /3, 0..1279 /5, 0..1791 /7).
+// (v_bfe_u32/i32, v_bitop3_b32, v_perm_b32, v_mul_u32_u24, packed 16-bit adds, v_sat_pk_u8_i16): the
+// decode path has no floating point and no MFMA work.  The exact-division
+// helpers are DETEX_HD so that tests/test_host_logic.py::test_intmath can compile them for the host
+// and prove them exhaustively equal to C integer division on the domains the reference's LUTs cover
+// (division-tables.c: 0..767 /3, 0..1279 /5, 0..1791 /7); the signed forms and the closed-form
+// weight / 16-bit-map helpers below them are the checked statements the decoders' faster biased
+// variants are tested against.
 #pragma once
 #include <stdint.h>
 
@@ -138,7 +140,6 @@ DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
 	const uint32_t x_lo = bfi(k1, b.w[2], b.w[0]), x_mid = bfi(k1, b.w[3], b.w[1]), x_hi = b.w[2] & ~k1;
 	return __builtin_amdgcn_alignbit(bfi(k0, x_hi, x_mid), bfi(k0, x_mid, x_lo), pos & 31u);
 }
-DH uint32_t extract_bits(const Bits128 &b, uint32_t pos, uint32_t n) { return ubfe(extract32(b, pos), 0, n); }
 
 // ---- workgroup-shared lookup tables in LDS ---------------------------------------------------------
 // A decoder that needs format tables declares `static DH void prepare()`: every kernel calls

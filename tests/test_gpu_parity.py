@@ -353,3 +353,37 @@ def test_unsupported_targets_fail_loudly(hiplib):
     ok, out = hiplib.linear(fmt, data, 64, 64, pixel_format=0x6735, out=out)    # FLOAT_RGBA16: unreachable in the reference too
     assert not ok and not out.any()
     assert "outside the block-decode path" in hiplib.error()
+
+
+# ---- re-entrancy of the host-pointer tier (the reference is re-entrant; per-thread stream + staging here) ----
+def test_host_api_concurrent_threads(hiplib, oracle):
+    """eight host threads decode different formats / sizes through detexDecompressTextureLinear and the leaf
+    functions at the same time (ctypes drops the GIL); every result and every thread-local error text is its own"""
+    import threading
+    names = ["BC1", "BPTC", "ETC2_EAC", "BPTC_FLOAT", "RGTC2", "EAC_SIGNED_R11", "BC3", "SIGNED_RGTC1"]
+    jobs = []
+    for k, name in enumerate(names):
+        fmt = F.BY_NAME[name]
+        w, h = 256 + 64 * k, 128 + 36 * (k % 3)           # some sizes are not multiples of 4 blocks wide
+        data = ol.stream_u(fmt, ((w + 3) // 4) * ((h + 3) // 4), seed=0x7EAD + k)
+        jobs.append((fmt, w, h, data, oracle.linear(fmt, data, w, h)))
+    errors = []
+
+    def work(k):
+        fmt, w, h, data, (ok_o, want) = jobs[k]
+        try:
+            for rep in range(6):
+                ok, out = hiplib.linear(fmt, data, w, h)
+                assert ok == ok_o and np.array_equal(out, want), (fmt.name, rep)
+                okb, outb = hiplib.block(fmt, data[:fmt.block_bytes])
+                okc, wantb = oracle.blocks(fmt, data[:fmt.block_bytes])
+                assert okb == bool(okc[0]) and (not okb or np.array_equal(outb, wantb[0])), (fmt.name, "leaf", rep)
+                if not ok:      # this thread's own error text, not a neighbour's
+                    assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+        except Exception as e:  # noqa
+            errors.append((names[k], repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
