@@ -119,6 +119,35 @@ DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t
 	}
 }
 
+// 64-bit pixels: a lane's texel row is 32 B, so a plain dwordx4 store writes 16 of every 32 bytes and the
+// line is completed by the NEXT instruction -- measured 2.5 TB/s for streaming stores (BC6H 217 us).  Each row
+// is transposed through 2 KiB of LDS per wave so that every store instruction covers one contiguous 1 KiB
+// run, as for the 32-bit formats.  Needs the wave's 64 blocks in one block row (width_in_blocks % 64 == 0;
+// then every wave is also full).  dst = this lane's block in image row 4*by.
+DH void store_rows_wide_pixels(uint8_t *dst, uint64_t pitch, const uint32_t (&o)[32]) {
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	__shared__ v4 xpose[4][128];
+	v4 *slab = xpose[threadIdx.x >> 6];
+	const uint32_t lane = threadIdx.x & 63u;
+	uint8_t *row0 = dst - (uint64_t)lane * 32u;		// start of the wave's 2 KiB row segment
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		slab[2 * lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
+		slab[2 * lane + 1] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+		// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
+		// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const v4 a = slab[lane], b = slab[64 + lane];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		v4 *out = reinterpret_cast<v4 *>(row0 + (uint64_t)r * pitch);
+		__builtin_nontemporal_store(a, out + lane);
+		__builtin_nontemporal_store(b, out + 64 + lane);
+	}
+}
+
 // decode + zero-fill on failure + epilogue; returns ok
 template <class Dec, int EPI, bool CHECKED>
 DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
@@ -151,33 +180,8 @@ __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ bl
 	split_index(i, width_in_blocks, by, bx);
 	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 	if constexpr (ROW == 8 && NT) {
-		// 64-bit pixels: a lane's row is 32 B, so a plain dwordx4 store writes 16 of every 32 bytes
-		// and the line is completed by the NEXT instruction -- measured 2.5 TB/s for streaming stores
-		// (BC6H 217 us).  Transpose each row through 2 KiB of LDS per wave so that every store
-		// instruction covers one contiguous 1 KiB run, as for the 32-bit formats.  Needs the wave's 64
-		// blocks in one block row (width_in_blocks % 64 == 0; then every wave is also full).
 		if ((width_in_blocks & 63u) == 0u) {
-			typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-			__shared__ v4 xpose[4][128];
-			v4 *slab = xpose[threadIdx.x >> 6];
-			const uint32_t lane = threadIdx.x & 63u;
-			uint8_t *row0 = dst - (uint64_t)lane * 32u;		// start of the wave's 2 KiB row segment
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				slab[2 * lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
-				slab[2 * lane + 1] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
-				// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
-				// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				const v4 a = slab[lane], b = slab[64 + lane];
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				v4 *out = reinterpret_cast<v4 *>(row0 + (uint64_t)r * pitch);
-				__builtin_nontemporal_store(a, out + lane);
-				__builtin_nontemporal_store(b, out + 64 + lane);
-			}
+			store_rows_wide_pixels(dst, pitch, o);
 			raise_status(!ok, status);
 			return;
 		}

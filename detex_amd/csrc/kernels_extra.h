@@ -41,6 +41,13 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	split_index(i, lv.width_in_blocks, by, bx);
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
 	if (lv.fast) {
+		if constexpr (ROW == 8) {
+			if ((lv.width_in_blocks & 63u) == 0u) {		// workgroup-uniform: a workgroup never spans two levels
+				store_rows_wide_pixels(dst, lv.pitch, o);
+				raise_status(!ok, status);
+				return;
+			}
+		}
 #pragma unroll
 		for (int r = 0; r < 4; r++) store_row<ROW, true>(dst + (uint64_t)r * lv.pitch, o + r * ROW);
 	} else {
