@@ -29,38 +29,94 @@ constexpr uint32_t bc7_desc(uint32_t ns, uint32_t pb, uint32_t rb, uint32_t isb,
 		uint32_t spb, uint32_t ib, uint32_t ib2) {
 	return ns | (pb << 2) | (rb << 5) | (isb << 7) | (cb << 8) | (ab << 11) | (epb << 15) | (spb << 16) | (ib << 17) | (ib2 << 20);
 }
-__constant__ uint32_t kBc7ModeDesc[8] = {
-	//       subsets part rot isel colour alpha endpoint-P shared-P index index2
-	bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0),
-	bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0),
-	bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
-	bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0),
-	bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3),
-	bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
-	bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0),
-	bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0),
+
+// Everything about a mode that does not depend on the block's contents, precomputed (decompress-bptc.c:24-43,
+// :45-71, :134-180): bit positions of the fields, their widths, the shift amounts of the 8-bit expansion, the
+// index widths and their weight constants.  For a per-lane mode the decoder fetches this record from LDS with a
+// few ds_read_b128 instead of deriving it from the descriptor word with ~50 VALU instructions per block.
+struct alignas(16) Bc7Layout {
+	uint32_t pos_part, pb, pos_rot, rb, pos_isel, isb;		// header fields
+	uint32_t pos_r, pos_g, pos_b, pos_a, pos_p, pos_idx, pos_idx2;	// channel words, P-bits, index streams
+	uint32_t cb, ab, off[6], offa[4];				// field widths, e*cb, e*ab
+	uint32_t has_p, epb, p_word_mask, p_double;			// p_word_mask: quirk A-2 (mode 6 keeps one P-bit); p_double: shared P-bit
+	uint32_t c_up, c_down, c_keep, a_up, a_down;
+	uint32_t alpha_keep, alpha_set;					// modes 0-3: alpha = 255
+	uint32_t ns, part_base, ib, ib2;				// part_base: +64 selects the three-subset table
+	uint32_t w_mul, w_add, w2_mul, w2_add;				// weight = byte 2 of index * mul + add, for ib and ib2
 };
+constexpr uint32_t bc7_weight_mul(uint32_t bits) { return bits == 2 ? 1398144u : (bits == 3 ? 599232u : 279680u); }
+constexpr uint32_t bc7_weight_add(uint32_t bits) { return bits == 2 ? 21846u : (bits == 3 ? 28089u : 30590u); }
+constexpr Bc7Layout bc7_layout(uint32_t mode, uint32_t desc) {
+	const uint32_t ns = desc & 3u, pb = (desc >> 2) & 7u, rb = (desc >> 5) & 3u, isb = (desc >> 7) & 1u;
+	const uint32_t cb = (desc >> 8) & 7u, ab = (desc >> 11) & 15u, epb = (desc >> 15) & 1u, spb = (desc >> 16) & 1u;
+	const uint32_t ib = (desc >> 17) & 7u, ib2 = (desc >> 20) & 3u;
+	Bc7Layout L = {};
+	L.pos_part = mode + 1u; L.pb = pb;
+	L.pos_rot = L.pos_part + pb; L.rb = rb;
+	L.pos_isel = L.pos_rot + rb; L.isb = isb;
+	const uint32_t chan = 2u * ns * cb;
+	L.pos_r = L.pos_isel + isb; L.pos_g = L.pos_r + chan; L.pos_b = L.pos_g + chan; L.pos_a = L.pos_b + chan;
+	L.pos_p = L.pos_a + 2u * ns * ab;
+	L.pos_idx = L.pos_p + epb * 2u * ns + spb * ns;
+	L.pos_idx2 = L.pos_idx + 16u * ib - ns;
+	L.cb = cb; L.ab = ab;
+	for (uint32_t e = 0; e < 6u; e++) L.off[e] = e * cb;
+	for (uint32_t e = 0; e < 4u; e++) L.offa[e] = e * ab;
+	L.has_p = epb | spb; L.epb = epb;
+	L.p_word_mask = mode == 6u ? 1u : 0xFFFFFFFFu;
+	L.p_double = (spb && !epb) ? 0xFFFFFFFFu : 0u;
+	const uint32_t cprec = cb + L.has_p, aprec = ab + epb;
+	L.c_up = 8u - cprec; L.c_down = (2u * cprec - 8u) & 31u;
+	L.c_keep = 0x010101u * ((1u << L.c_up) - 1u);
+	L.a_up = (8u - aprec) & 31u; L.a_down = (2u * aprec - 8u) & 31u;
+	L.alpha_keep = mode < 4u ? 0u : 0xFFFFFFFFu; L.alpha_set = mode < 4u ? 0xFF000000u : 0u;
+	L.ns = ns; L.part_base = ns == 3u ? 64u : 0u; L.ib = ib; L.ib2 = ib2;
+	L.w_mul = bc7_weight_mul(ib); L.w_add = bc7_weight_add(ib);
+	L.w2_mul = bc7_weight_mul(ib2); L.w2_add = bc7_weight_add(ib2);
+	return L;
+}
+constexpr uint32_t kBc7Desc[8] = {
+	//       subsets part rot isel colour alpha endpoint-P shared-P index index2
+	bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0), bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0), bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
+	bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0), bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3), bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
+	bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0), bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0) };
+__constant__ Bc7Layout kBc7Layouts[8] = {
+	bc7_layout(0, kBc7Desc[0]), bc7_layout(1, kBc7Desc[1]), bc7_layout(2, kBc7Desc[2]), bc7_layout(3, kBc7Desc[3]),
+	bc7_layout(4, kBc7Desc[4]), bc7_layout(5, kBc7Desc[5]), bc7_layout(6, kBc7Desc[6]), bc7_layout(7, kBc7Desc[7]),
+};
+static_assert(sizeof(Bc7Layout) % 16 == 0, "record is fetched with 16-byte LDS reads");
 
 // workgroup copies in LDS (dev_common.h: prepare_tables).  anchor_p1[i] = kAnchorWords[i] | kPartition1Bit[i] << 16
-struct BptcTables { uint32_t part2[128]; uint32_t anchor_p1[64]; uint32_t desc[8]; };
+struct BptcTables { uint32_t part2[128]; uint32_t anchor_p1[64]; Bc7Layout layout[8]; };
 #if defined(__HIPCC__)
 DH BptcTables &bptc_tables() { __shared__ BptcTables t; return t; }
-DH void bptc_prepare() {
+DH void bptc_prepare(bool with_layouts) {
 	BptcTables &t = bptc_tables();
 	const uint32_t k = threadIdx.x;
 	if (k < 128u) t.part2[k] = kPartition2Bit[k];
 	else if (k < 192u) t.anchor_p1[k - 128u] = (uint32_t)kAnchorWords[k - 128u] | ((uint32_t)kPartition1Bit[k - 128u] << 16);
-	else if (k < 200u) t.desc[k - 192u] = kBc7ModeDesc[k - 192u];
+	if (with_layouts) {
+		constexpr uint32_t kWords = 8u * sizeof(Bc7Layout) / 4u;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(kBc7Layouts);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(t.layout);
+		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
+	}
 	__syncthreads();
 }
 DH uint32_t bptc_part2(uint32_t i) { return bptc_tables().part2[i]; }
 DH uint32_t bptc_anchor_p1(uint32_t i) { return bptc_tables().anchor_p1[i]; }
-DH uint32_t bptc_desc(uint32_t m) { return bptc_tables().desc[m]; }
+DH const Bc7Layout &bptc_layout(uint32_t m) {
+	// one opaque byte offset per lane: the record's fields then come as immediate offsets of a few wide LDS
+	// reads (left to itself the compiler rebuilds mode * sizeof + field offset with a v_mad per field)
+	uint32_t off = m * (uint32_t)sizeof(Bc7Layout);
+	asm("" : "+v"(off));
+	return *reinterpret_cast<const Bc7Layout *>(reinterpret_cast<const char *>(bptc_tables().layout) + off);
+}
 #else
-DH void bptc_prepare() {}
+DH void bptc_prepare(bool) {}
 DH uint32_t bptc_part2(uint32_t i) { return kPartition2Bit[i]; }
 DH uint32_t bptc_anchor_p1(uint32_t i) { return (uint32_t)kAnchorWords[i] | ((uint32_t)kPartition1Bit[i] << 16); }
-DH uint32_t bptc_desc(uint32_t m) { return kBc7ModeDesc[m]; }
+DH const Bc7Layout &bptc_layout(uint32_t m) { return kBc7Layouts[m]; }
 #endif
 
 // weight(index) for a per-lane index width: (64*i + d/2) / d as multiply-shift (dev_common.h)
@@ -116,7 +172,7 @@ DH WeightMad weight_mad(uint32_t bits) {
 //   2  as 1, and block fields are fetched from an LDS copy of the block (two dwords + v_alignbit)
 template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
-	static DH void prepare() { bptc_prepare(); }
+	static DH void prepare() { bptc_prepare(true); }
 
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		const uint32_t low = blk.x & 0xFFu;
@@ -127,14 +183,10 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 			if (mode >= 4 && (flags & kFlagOpaqueOnly)) return false;
 			if (mode < 4 && (flags & kFlagNonOpaqueOnly)) return false;
 		}
-		constexpr uint32_t kDesc[8] = {
-			bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0), bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0), bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
-			bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0), bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3), bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
-			bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0), bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0) };
-		const uint32_t desc = FIXED_MODE >= 0 ? kDesc[FIXED_MODE >= 0 ? FIXED_MODE : 0] : bptc_desc(mode);
-		const uint32_t ns = desc & 3u, pb = ubfe(desc, 2, 3), rb = ubfe(desc, 5, 2), isb = ubfe(desc, 7, 1);
-		const uint32_t cb = ubfe(desc, 8, 3), ab = ubfe(desc, 11, 4), epb = ubfe(desc, 15, 1), spb = ubfe(desc, 16, 1);
-		const uint32_t ib = ubfe(desc, 17, 3), ib2 = ubfe(desc, 20, 2);
+		// the mode's layout record: compile-time for a fixed mode, one LDS record for a per-lane mode
+		constexpr Bc7Layout kFixed = bc7_layout(FIXED_MODE >= 0 ? FIXED_MODE : 0, kBc7Desc[FIXED_MODE >= 0 ? FIXED_MODE : 0]);
+		const Bc7Layout &L = FIXED_MODE >= 0 ? kFixed : bptc_layout(mode);
+		const uint32_t ns = L.ns, cb = L.cb, ab = L.ab, epb = L.epb, has_p = L.has_p, ib = L.ib, ib2 = L.ib2;
 		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
 		// IMPL 2: the block's dwords as per-lane LDS rows (rows 4, 5 read as zero: bits beyond 127)
 		LaneRows<uint32_t, IMPL == 2 ? 6 : 1, 71> rows;
@@ -148,33 +200,23 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		};
 
 		// header fields all lie in the first 14 bits
-		uint32_t pos = mode + 1u;
-		const uint32_t part = ubfe(blk.x, pos, pb); pos += pb;
-		const uint32_t rot = ubfe(blk.x, pos, rb); pos += rb;
-		const uint32_t isel = ubfe(blk.x, pos, isb); pos += isb;
+		const uint32_t part = ubfe(blk.x, L.pos_part, L.pb);
+		const uint32_t rot = ubfe(blk.x, L.pos_rot, L.rb);
+		const uint32_t isel = ubfe(blk.x, L.pos_isel, L.isb);
 
 		// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values) -- :74-132
-		const uint32_t chan = 2u * ns * cb;			// <= 30 bits per colour channel
-		const uint32_t wr = field32(pos), wg = field32(pos + chan), wb = field32(pos + 2u * chan);
-		pos += 3u * chan;
-		const uint32_t wa = field32(pos);
-		pos += 2u * ns * ab;
-		uint32_t pw = field32(pos);				// P-bits: per endpoint, or per subset (mode 1)
-		pw = mode == 6u ? (pw & 1u) : pw;			// QUIRK A-2 (decompress-bptc.c:142-146)
-		pos += epb * 2u * ns + spb * ns;
+		const uint32_t wr = field32(L.pos_r), wg = field32(L.pos_g), wb = field32(L.pos_b), wa = field32(L.pos_a);
+		uint32_t pw = field32(L.pos_p) & L.p_word_mask;	// P-bits; QUIRK A-2: mode 6 keeps only the first (:142-146)
+		const uint32_t pos = L.pos_idx;
 
 		// expand to 8 bits: append the P-bit, shift the MSB to bit 7, replicate the top bits (:136-180)
-		const uint32_t has_p = epb | spb;
-		const uint32_t cprec = cb + has_p, aprec = ab + epb;
-		const uint32_t c_up = 8u - cprec, c_down = (2u * cprec - 8u) & 31u;
-		const uint32_t a_up = (8u - aprec) & 31u, a_down = (2u * aprec - 8u) & 31u;
-		const uint32_t c_keep = 0x010101u * ((1u << c_up) - 1u);
+		const uint32_t c_up = L.c_up, c_down = L.c_down, c_keep = L.c_keep, a_up = L.a_up, a_down = L.a_down;
 		// P-bit of endpoint e at bit e: per-endpoint P-bits as stored, a shared P-bit (mode 1) doubled
-		const uint32_t pw_e = (epb ? pw : ((pw & 1u) * 3u) | ((pw & 2u) * 6u)) & (0u - has_p);
+		const uint32_t pw_e = bfi(L.p_double, ((pw & 1u) * 3u) | ((pw & 2u) * 6u), pw) & (0u - has_p);
 		uint32_t ep[6];
 #pragma unroll
 		for (int e = 0; e < 6; e++) {
-			const uint32_t off = (uint32_t)e * cb, offa = (uint32_t)e * ab;
+			const uint32_t off = L.off[e];
 			// (three-input logic goes through v_bitop3_b32 -- dev_common.h: and_or / or3 -- at 2.5 cycles instead of 4.4)
 			uint32_t x = or3(ubfe(wr, off, cb), ubfe(wg, off, cb) << 8, ubfe(wb, off, cb) << 16);
 			const uint32_t p = ubfe(pw_e, e, 1);
@@ -182,16 +224,16 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 			x = and_or(x >> c_down, c_keep, x << c_up);		// each byte holds cprec bits: nothing crosses a byte
 			uint32_t a = 0xFF000000u;				// :176-179; modes with alpha have at most two subsets
 			if (e < 4) {
-				a = ubfe(wa, offa, ab);
+				a = ubfe(wa, L.offa[e], ab);
 				a = and_or(p, epb, a << epb);
 				a = ((a << a_up) | (a >> a_down)) << 24;	// bits above the byte fall off the top
-				a = mode < 4u ? 0xFF000000u : a;
+				a = and_or(a, L.alpha_keep, L.alpha_set);	// modes 0-3 are opaque
 			}
 			ep[e] = x | a;
 		}
 
 		// partition + anchors (:391-400)
-		const uint32_t pword = ns == 1u ? 0u : bptc_part2(part + (ns == 3u ? 64u : 0u));
+		const uint32_t pword = ns == 1u ? 0u : bptc_part2(part + L.part_base);
 		const uint32_t an = bptc_anchor_p1(part);
 		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
 		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
@@ -199,7 +241,7 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		const uint32_t gather = rot == 0u ? 0x07050301u : (rot == 1u ? 0x01050307u : (rot == 2u ? 0x03050701u : 0x05070301u));
 		// index streams, LSB-first: primary (16*ib - ns bits), then, for modes 4/5, the secondary one
 		// (16*ib2 - 1 bits) -- :401-480
-		const uint32_t pos2 = pos + 16u * ib - ns;
+		const uint32_t pos2 = L.pos_idx2;
 		const bool two = ib2 != 0u, swap = two && isel != 0u;
 		const bool any_two = FIXED_MODE >= 0 ? (FIXED_MODE == 4 || FIXED_MODE == 5) : (__builtin_amdgcn_ballot_w64(two) != 0);
 
@@ -253,18 +295,19 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		}
 		// colour stream C and alpha stream A: C is the primary stream unless the index-selection bit
 		// swaps them (:374-375, 452-480); only modes 4/5 have an A stream (one subset, anchor = texel 0)
-		const uint32_t ibc = swap ? ib2 : ib, iba = swap ? ib : ib2;
-		const uint32_t pos_c = swap ? pos2 : pos, pos_a = swap ? pos : pos2;
+		const uint32_t sm = cond_to_mask(swap);
+		const uint32_t ibc = bfi(sm, ib2, ib), iba = bfi(sm, ib, ib2);
+		const uint32_t pos_c = bfi(sm, pos2, pos), pos_a = bfi(sm, pos, pos2);
 		// Each stream is read through two 32-bit windows: texels 0-7 consume at most 31 bits (texel 0 is
 		// always an anchor), texels 8-15 start where they ended -- so advancing a stream is one plain shift.
 		const uint32_t half_c = 8u * ibc - (uint32_t)__builtin_popcount(amask & 0xFFu);
 		const uint32_t c_lo = field32(pos_c), c_hi = field32(pos_c + half_c);
-		const WeightMad wm_c = weight_mad(ibc);
+		const WeightMad wm_c = { bfi(sm, L.w2_mul, L.w_mul), bfi(sm, L.w2_add, L.w_add) };
 		// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
 		if (any_two) {
 			const uint32_t half_a = (8u * iba - 1u) & 31u;
 			const uint32_t a_lo = field32(pos_a), a_hi = field32(pos_a + half_a);
-			const WeightMad wm_a = weight_mad(iba);
+			const WeightMad wm_a = { bfi(sm, L.w_mul, L.w2_mul), bfi(sm, L.w_add, L.w2_add) };
 			const uint32_t sel_ba = two ? 0x0C060C02u : 0x0C020C02u;	// alpha weight from the A stream, or the colour weight again
 			const uint32_t width_a = iba & 31u;
 			uint32_t cw = c_lo, aw = a_lo;

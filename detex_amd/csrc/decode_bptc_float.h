@@ -164,7 +164,7 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 DH Bc6hModeWords *bc6h_mode_words_lds() { __shared__ Bc6hModeWords t[14]; return t; }
 DH void bc6h_prepare() {
 	if (threadIdx.x >= 200u && threadIdx.x < 214u) bc6h_mode_words_lds()[threadIdx.x - 200u] = kBc6hModeWords[threadIdx.x - 200u];
-	bptc_prepare();		// ends in the workgroup barrier
+	bptc_prepare(false);	// ends in the workgroup barrier
 }
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_mode_words_lds()[mode]; }
 #else

@@ -7,7 +7,7 @@ K="$1"; shift
 timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "$K" 2>&1 | tail -6 | tee $OUT/pytest_ab.log
 for fv in "$@"; do
   f=${fv%%:*}; v=${fv##*:}
-  timeout 300 python bench.py --no-cpu --format $f --variant $v --steps 50 --warmup 5 2>>$OUT/ab.err > $OUT/ab_${f}_v$v.json
+  timeout 300 python bench.py --no-cpu --format $f --variant $v --steps 200 --warmup 400 2>>$OUT/ab.err > $OUT/ab_${f}_v$v.json
   python - <<PY
 import json
 d=json.load(open("$OUT/ab_${f}_v$v.json"))
@@ -16,7 +16,7 @@ PY
 done
 # tiled (block-major) layout of the formats named in $TILED
 for f in ${TILED:-}; do
-  timeout 300 python bench.py --no-cpu --format $f --layout tiled --steps 50 --warmup 5 2>>$OUT/ab.err > $OUT/ab_${f}_tiled.json
+  timeout 300 python bench.py --no-cpu --format $f --layout tiled --steps 200 --warmup 400 2>>$OUT/ab.err > $OUT/ab_${f}_tiled.json
   python - <<PY
 import json
 d=json.load(open("$OUT/ab_${f}_tiled.json"))
