@@ -250,30 +250,42 @@ __global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ bl
 	} else {
 		// A lane's block is ROW vectors = 16*ROW contiguous bytes, so a direct store instruction would write
 		// 16 bytes out of every 16*ROW: partial lines, measured 91 us against 43 us for the linear layout on
-		// BC1 8192^2.  The wave's blocks are contiguous in the output, so they are staged in LDS in output
-		// order and written back as ROW instructions of one contiguous 1 KiB run each.  Lanes past the end
-		// of the stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
-		__shared__ v4 stage[4][64 * ROW];
+		// BC1 8192^2.  The wave's blocks are contiguous in the output, so they go through LDS and are written
+		// back as ROW instructions of one contiguous 1 KiB run each.  LDS layout [vector k of the block][block],
+		// row stride GROUP + 16/ROW vectors: the writes (consecutive lanes, consecutive 16-byte slots) and the
+		// transposed reads (output vector e = block*ROW + k) are both bank-conflict free; a lane-major layout
+		// costs an 8-way conflict on every access for the 128-byte BC6H blocks.  64-bit pixels take two passes
+		// of 32 blocks so that 17 KiB per workgroup suffice for every pixel size.  Lanes past the end of the
+		// stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
+		constexpr int PASSES = ROW == 8 ? 2 : 1, GROUP = 64 / PASSES;		// blocks per pass
+		constexpr int STRIDE = GROUP + (16 % ROW == 0 ? 16 / ROW : 5);
+		__shared__ v4 stage[4][ROW * STRIDE];
 		v4 *slab = stage[threadIdx.x >> 6];
 		const uint32_t lane = threadIdx.x & 63u;
 		uint32_t o[4 * ROW];
 		bool ok = true;
-		if (live) {
-			ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
-#pragma unroll
-			for (int k = 0; k < ROW; k++) slab[lane * ROW + k] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
-		}
-		// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (live) ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
 		const uint32_t first = i - lane;						// the wave's first block
 		const uint32_t vectors = (first < n_blocks ? min(64u, n_blocks - first) : 0u) * ROW;
 		v4 *out = reinterpret_cast<v4 *>(pixels) + (uint64_t)first * ROW;
 #pragma unroll
-		for (int k = 0; k < ROW; k++) {
-			const uint32_t e = (uint32_t)k * 64u + lane;
-			if (e < vectors) __builtin_nontemporal_store(slab[e], out + e);
+		for (int p = 0; p < PASSES; p++) {
+			if (live && (PASSES == 1 || lane / GROUP == (uint32_t)p)) {
+#pragma unroll
+				for (int k = 0; k < ROW; k++) slab[k * STRIDE + lane % GROUP] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+			}
+			// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+			for (int j = 0; j < GROUP * ROW / 64; j++) {
+				const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
+				const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
+				if (g < vectors) __builtin_nontemporal_store(slab[(e % ROW) * STRIDE + e / ROW], out + g);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
 		if (!live) return;
 		if (ok_out) ok_out[i] = ok ? 1 : 0;
