@@ -126,20 +126,24 @@ DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t
 // then every wave is also full).  dst = this lane's block in image row 4*by.
 DH void store_rows_wide_pixels(uint8_t *dst, uint64_t pitch, const uint32_t (&o)[32]) {
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-	__shared__ v4 xpose[4][128];
+	// [half of the lane's 32-byte row][lane], the second half 72 vectors on: writes (consecutive lanes) and
+	// transposed reads (output vector e = 2*lane' + half) are both bank-conflict free
+	constexpr int STRIDE = 72;
+	__shared__ v4 xpose[4][STRIDE + 64];
 	v4 *slab = xpose[threadIdx.x >> 6];
 	const uint32_t lane = threadIdx.x & 63u;
 	uint8_t *row0 = dst - (uint64_t)lane * 32u;		// start of the wave's 2 KiB row segment
+	const uint32_t src_a = (lane & 1u) * STRIDE + (lane >> 1), src_b = src_a + 32u;	// vectors e = lane and e = 64 + lane
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
-		slab[2 * lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
-		slab[2 * lane + 1] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+		slab[lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
+		slab[STRIDE + lane] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
 		// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
 		// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const v4 a = slab[lane], b = slab[64 + lane];
+		const v4 a = slab[src_a], b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		v4 *out = reinterpret_cast<v4 *>(row0 + (uint64_t)r * pitch);
