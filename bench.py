@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--format", default="BC1")
     ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
     ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
+    ap.add_argument("--strong-image", type=int, default=0,
+                    help="strong scaling: ONE S x S image sharded by block rows over the ranks (BASELINE north_star: 32768); "
+                         "each rank decodes its S x S/N band, value = S*S*steps/time, \"scaling\": \"strong\"")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (include/detexhip.h)")
     ap.add_argument("--stream", default="U", choices=["U", "M"])
     ap.add_argument("--layout", default="linear", choices=["linear", "tiled"],
@@ -190,6 +193,10 @@ def main():
     W = H = args.size
     if args.band_height:
         H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
+    if args.strong_image:
+        from detex_amd import sharding
+        shard = sharding.shard_of(rank, world, fmt, args.strong_image, args.strong_image)
+        W, H = args.strong_image, (shard.row1 - shard.row0) * 4
     data, d_blocks, d_out, wall, launch_ms = run_format(fmt, W, H, args.steps, args.warmup)
     blocks = (W // 4) * (H // 4)
     pf, tpx = target_of(fmt)
@@ -216,7 +223,7 @@ def main():
     result = {
         "metric": "Gpixel/s decoded (%s -> %s, %dx%d per GPU, device-resident)" % (fmt.name, F.target_name(fmt), W, H),
         "value": round(gpix, 3), "unit": "Gpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong" if args.strong_image else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, "
                                "sharded by block rows: one %d-row band per GPU" % (fmt.name, F.target_name(fmt), W, H, args.stream, H),
