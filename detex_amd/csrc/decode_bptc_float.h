@@ -225,6 +225,13 @@ DH int32_t bc6h_unquantize_signed(int32_t x, uint32_t epb) {
 	return epb >= 16u ? x : s;
 }
 
+// both signed 16-bit lanes: two's complement -> sign-magnitude half of trunc(v * 31 / 32) (decompress-bptc-float.c:576-609)
+DH uint32_t bc6h_sign_magnitude_pk(uint32_t p) {
+	const uint32_t a = pk_max16(p, pk_sub16(0u, p));				// |v| (0x8000 stays 0x8000: read as unsigned below)
+	const uint32_t m = pk_sub16(a, pk_lshr16(pk_add16(a, 0x001F001Fu), 5));	// |v| - ceil(|v| / 32) <= 0x7C00
+	return m | and3(pk_add16(m, 0x7FFF7FFFu), p, 0x80008000u);
+}
+
 // SWITCH_SCATTER = true keeps the per-mode switch (cheaper when a whole wave shares one mode); the
 // default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
@@ -305,7 +312,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			row_a.put(s, ra);
 			row_b.put(s, rb);
 		}
-		uint32_t win = lo;
+		uint32_t win = lo, b_even = 0;
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			if (i == 8) win = hi;
@@ -316,21 +323,29 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			const uint4 ra = row_a.get(sub);
 			const uint2 rb = row_b.get(sub);
 			const int32_t bs[3] = { (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z }, df[3] = { (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y };
-			uint32_t h[3];
+			int32_t v[3];
 #pragma unroll
-			for (int c = 0; c < 3; c++) {
-				const int32_t v = (bs[c] + __mul24(w, df[c])) >> 6;
-				if (SIGNED) {				// :576-609 sign-magnitude half: m = (|v|*31)>>5, sign only if m != 0
-					const uint32_t sg = (uint32_t)(v >> 31);
-					const uint32_t m = (uint32_t)__mul24((int32_t)(((uint32_t)v ^ sg) - sg), 31) >> 5;	// m <= 0x7BFF
-					h[c] = m | ((m + 0x7FFFu) & sg & 0x8000u);	// bit 15 of m + 0x7FFF is set iff m != 0
+			for (int c = 0; c < 3; c++) v[c] = (bs[c] + __mul24(w, df[c])) >> 6;
+			if (SIGNED) {
+				// :576-609 sign-magnitude half: m = (|v|*31)>>5 = |v| - ceil(|v|/32), sign bit only if m != 0.  Every v fits a
+				// signed 16-bit lane (|v| <= 0x8000, and 0x8000 still comes out right in the unsigned steps), so R,G of this
+				// texel and B of two neighbouring texels are finished two per VGPR; bit 15 of m + 0x7FFF is set iff m != 0.
+				d[2 * i] = bc6h_sign_magnitude_pk(pack16((uint32_t)v[0], (uint32_t)v[1]));
+				if ((i & 1) == 0) {
+					b_even = (uint32_t)v[2];
 				} else {
-					h[c] = (uint32_t)__mul24(v, 31) >> 6;	// :613-621 (v >= 0: /64 == >>6)
+					const uint32_t hb = bc6h_sign_magnitude_pk(pack16(b_even, (uint32_t)v[2]));
+					d[2 * i - 1] = hb & 0xFFFFu;		// X = 0
+					d[2 * i + 1] = hb >> 16;
 				}
+			} else {
+				uint32_t h[3];
+#pragma unroll
+				for (int c = 0; c < 3; c++) h[c] = (uint32_t)__mul24(v[c], 31) >> 6;	// :613-621 (v >= 0: /64 == >>6)
+				d[2 * i] = perm(h[1], h[0], 0x05040100u);	// every h < 2^16; v_perm keeps the compiler from fusing
+										// the shift into a v_mul_lo_u32
+				d[2 * i + 1] = h[2];				// X = 0
 			}
-			d[2 * i] = perm(h[1], h[0], 0x05040100u);	// every h < 2^16; v_perm keeps the compiler from fusing
-									// the shift into a v_mul_lo_u32
-			d[2 * i + 1] = h[2];				// X = 0
 		}
 		return true;
 	}

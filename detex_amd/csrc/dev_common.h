@@ -81,10 +81,12 @@ DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bi
 // (a & b) | c and a | b | c through the same instruction
 DH uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
 DH uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
+DH uint32_t and3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80); }
 #else
 DH uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 DH uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 DH uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
+DH uint32_t and3(uint32_t a, uint32_t b, uint32_t c) { return a & b & c; }
 #endif
 // byte permute: result byte i = byte sel[i] of the 8-byte pool {s0 (4..7), s1 (0..3)}; 0x0C -> 0x00
 DH uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
@@ -104,6 +106,9 @@ DH uint32_t pk_add16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) + t
 DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) - to_pk_i16(b)); }
 DH uint32_t pk_ashr16(uint32_t a, int s) { return of_pk_i16(to_pk_i16(a) >> (int16_t)s); }
 DH uint32_t pk_mul16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) * to_pk_i16(b)); }
+DH uint32_t pk_max16(uint32_t a, uint32_t b) { return of_pk_i16(__builtin_elementwise_max(to_pk_i16(a), to_pk_i16(b))); }	// signed
+typedef uint16_t pk_u16 __attribute__((ext_vector_type(2)));
+DH uint32_t pk_lshr16(uint32_t a, int s) { pk_u16 v; __builtin_memcpy(&v, &a, 4); v = v >> (uint16_t)s; uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
 // both signed 16-bit lanes clamped to 0..255: lane 0 -> byte 0, lane 1 -> byte 1.  Only bytes 0
 // and 1 of the result may be used (callers gather them with v_perm_b32).
 DH uint32_t sat_u8_pk16(uint32_t a) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a)); return r; }
@@ -114,6 +119,11 @@ DH uint32_t pk_ashr16(uint32_t a, int s) {
 	return ((uint32_t)((int32_t)(int16_t)(a & 0xFFFFu) >> s) & 0xFFFFu) | ((uint32_t)((int32_t)(int16_t)(a >> 16) >> s) << 16);
 }
 DH uint32_t pk_mul16(uint32_t a, uint32_t b) { return ((a * b) & 0xFFFFu) | (((a >> 16) * (b >> 16)) << 16); }
+DH uint32_t pk_max16(uint32_t a, uint32_t b) {
+	const int32_t al = (int16_t)(a & 0xFFFFu), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xFFFFu), bh = (int16_t)(b >> 16);
+	return ((uint32_t)max(al, bl) & 0xFFFFu) | ((uint32_t)max(ah, bh) << 16);
+}
+DH uint32_t pk_lshr16(uint32_t a, int s) { return ((a & 0xFFFFu) >> s) | (((a >> 16) >> s) << 16); }
 DH uint32_t sat_u8_pk16(uint32_t a) {
 	const int32_t lo = (int16_t)(a & 0xFFFFu), hi = (int16_t)(a >> 16);
 	return (uint32_t)clampi(lo, 0, 255) | ((uint32_t)clampi(hi, 0, 255) << 8) | 0xDEAD0000u;	// poison the unspecified half

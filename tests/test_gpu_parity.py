@@ -355,6 +355,23 @@ def test_unsupported_targets_fail_loudly(hiplib):
     assert "outside the block-decode path" in hiplib.error()
 
 
+def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
+    """interpolated value -32768 -> half 0xFC00 (see tests/test_host_logic.py for the fixture)"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME["BPTC_SIGNED_FLOAT"]
+    blocks = np.load(os.path.join(os.path.dirname(__file__), "golden", "bc6h_signed_extreme_blocks.npy"))
+    ok_o, want = oracle.blocks(fmt, blocks)
+    out, ok = binding.decompress_blocks_device(fmt, _dev(torch, blocks), len(blocks))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(len(blocks), -1), want)
+    data = np.resize(blocks.reshape(-1), (256 // 4) * (64 // 4) * 16)      # the same blocks through the linear kernel
+    _, want_l = oracle.linear(fmt, data, 256, 64)
+    got = binding.decompress_linear_device(fmt, _dev(torch, data), 256, 64)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want_l)
+
+
 # ---- re-entrancy of the host-pointer tier (the reference is re-entrant; per-thread stream + staging here) ----
 def test_host_api_concurrent_threads(hiplib, oracle):
     """eight host threads decode different formats / sizes through detexDecompressTextureLinear and the leaf

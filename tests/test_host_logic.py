@@ -127,6 +127,18 @@ def test_alternative_decoders_under_emulation(alt, name, emul, oracle, forced_ve
         assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
 
 
+def test_signed_bc6h_extreme_magnitudes_under_emulation(emul, oracle):
+    """mode-13 blocks whose interpolated value reaches -32768 (sign-magnitude half 0xFC00): the packed 16-bit
+    finish of the signed BC6H kernel must treat |v| = 0x8000 as unsigned (tests/golden/bc6h_signed_extreme_blocks.npy:
+    64 blocks found by random search, expected values from the oracle)"""
+    fmt = F.BY_NAME["BPTC_SIGNED_FLOAT"]
+    blocks = np.load(os.path.join(ROOT, "tests", "golden", "bc6h_signed_extreme_blocks.npy"))
+    ok_o, out_o = oracle.blocks(fmt, blocks)
+    assert (out_o.view(np.uint16) == 0xFC00).any(axis=1).all()
+    ok_e, out_e = emul(fmt, blocks)
+    assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
+
+
 # ---- sharding -----------------------------------------------------------------------------------------
 def test_shard_arithmetic_tiles_the_texture_exactly():
     for fmt in (F.BY_NAME["BC1"], F.BY_NAME["BPTC_FLOAT"], F.BY_NAME["RGTC1"]):
