@@ -372,6 +372,42 @@ def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), want_l)
 
 
+def test_device_tier_is_graph_capturable(torch_cuda, oracle):
+    """a device-tier call is one asynchronous launch with no allocation or synchronisation inside, so it
+    can be captured into a hipGraph: capture three decodes (linear, tiled, mip levels via separate calls), replay twice
+    on fresh inputs and compare"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fa, fb = F.BY_NAME["BC1"], F.BY_NAME["BPTC"]
+    W, H = 512, 256
+    n = (W // 4) * (H // 4)
+    in_a = torch.zeros(n * fa.block_bytes, dtype=torch.uint8, device="cuda")
+    in_b = torch.zeros(n * fb.block_bytes, dtype=torch.uint8, device="cuda")
+    out_a = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+    out_b = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+    out_t = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    binding.decompress_linear_device(fa, in_a, W, H, out=out_a)      # warm-up outside the capture (module load)
+    binding.decompress_linear_device(fb, in_b, W, H, out=out_b, status=status)
+    binding.decompress_tiled_device(fb, in_b, W // 4, H // 4, out=out_t)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        binding.decompress_linear_device(fa, in_a, W, H, out=out_a)
+        binding.decompress_linear_device(fb, in_b, W, H, out=out_b, status=status)
+        binding.decompress_tiled_device(fb, in_b, W // 4, H // 4, out=out_t)
+    for rep in range(2):
+        da = ol.stream_u(fa, n, seed=0x6A0 + rep); db = ol.stream_u(fb, n, seed=0x6B0 + rep)
+        in_a.copy_(torch.from_numpy(da)); in_b.copy_(torch.from_numpy(db))
+        status.zero_(); out_a.zero_(); out_b.zero_(); out_t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out_a.cpu().numpy(), oracle.linear(fa, da, W, H)[1]), rep
+        ok_b, want_b = oracle.linear(fb, db, W, H)
+        assert np.array_equal(out_b.cpu().numpy(), want_b) and bool(status.item() == 0) == ok_b, rep
+        assert np.array_equal(out_t.cpu().numpy(), oracle.tiled(fb, db, W // 4, H // 4)[1]), rep
+
+
 # ---- re-entrancy of the host-pointer tier (the reference is re-entrant; per-thread stream + staging here) ----
 def test_host_api_concurrent_threads(hiplib, oracle):
     """eight host threads decode different formats / sizes through detexDecompressTextureLinear and the leaf
