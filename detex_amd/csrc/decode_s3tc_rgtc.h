@@ -141,34 +141,67 @@ DH void rgtc_channel_u8(uint32_t w0, uint32_t w1, uint32_t (&rows)[4]) {
 }
 
 // one signed RGTC channel -> eight dwords of two 16-bit texels each (decompress-rgtc.c:84-130).
-// Every quantity is kept biased so the arithmetic stays unsigned: a ramp value q in [-127,127] is carried as
-// n = q + 127, the reference's truncating /7 and /5 (detex.h:966-982) become floor divisions of
-// x + 128*d + (x < 0 ? d-1 : 0), and the 16-bit map (v+127)*65535/254 - 32768 is
-// (n*258 + floor(3n/254)) ^ 0x8000 with floor(3n/254) = (n*387 + 6) >> 15 on 0..254 (all three identities are
-// checked exhaustively in tests/test_host_logic.py).
-DH uint32_t rgtc_biased_to_u16(uint32_t n) { return DETEX_UMUL24(n, 258u) + ((DETEX_UMUL24(n, 387u) + 6u) >> 15); }
+// A ramp entry is  map16(trunc(((d-k)*e0 + k*e1) / d)),  d = 7 or 5, with the reference's truncating division
+// (detex.h:966-982) and map16(q) = (q+127)*65535/254 - 32768.  The numerator spans only [-127*d, 127*d], so each
+// entry is ONE lookup in a table indexed by the biased numerator (3.5 + 2.5 KiB of 16-bit values, generated at
+// compile time, copied to LDS once per workgroup): per entry one v_mad_u32_u24 for the byte offset and a
+// ds_read_u16, instead of a division, a sign fix-up and the 16-bit map in VALU arithmetic (the reference itself
+// divides through lookup tables, division-tables.c).  Values are kept with the sign bit flipped (unsigned order).
+constexpr uint32_t rgtc_map16_flipped(int32_t q) {		// q in [-127, 127]
+	const uint32_t n = (uint32_t)(q + 127);
+	return (n * 258u + ((n * 387u + 6u) >> 15)) & 0xFFFFu;		// == map16(q) ^ 0x8000, tests/test_host_logic.py
+}
+struct alignas(16) RgtcSignedTables {
+	uint16_t t7[1792];	// index x + 896, x = (7-k)*e0 + k*e1
+	uint16_t t5[1280];	// index x + 640, x = (5-k)*e0 + k*e1
+	uint16_t map[256];	// index q + 127
+};
+constexpr RgtcSignedTables rgtc_signed_tables() {
+	RgtcSignedTables t = {};
+	for (int y = 0; y < 1792; y++) { const int q = (y - 896) / 7; t.t7[y] = (uint16_t)rgtc_map16_flipped(q < -127 ? -127 : (q > 127 ? 127 : q)); }
+	for (int y = 0; y < 1280; y++) { const int q = (y - 640) / 5; t.t5[y] = (uint16_t)rgtc_map16_flipped(q < -127 ? -127 : (q > 127 ? 127 : q)); }
+	for (int n = 0; n < 256; n++) t.map[n] = (uint16_t)rgtc_map16_flipped(n > 254 ? 127 : n - 127);
+	return t;
+}
+__constant__ RgtcSignedTables kRgtcSignedTables = rgtc_signed_tables();
+static_assert(sizeof(RgtcSignedTables) % 16 == 0, "copied with 16-byte moves");
+#if defined(__HIPCC__)
+DH RgtcSignedTables &rgtc_signed_lds() { __shared__ RgtcSignedTables t; return t; }
+DH void rgtc_signed_prepare() {
+	const uint4 *src = reinterpret_cast<const uint4 *>(&kRgtcSignedTables);
+	uint4 *dst = reinterpret_cast<uint4 *>(&rgtc_signed_lds());
+	for (uint32_t k = threadIdx.x; k < sizeof(RgtcSignedTables) / 16u; k += 256u) dst[k] = src[k];
+	__syncthreads();
+}
+DH const RgtcSignedTables &rgtc_signed() { return rgtc_signed_lds(); }
+#else
+DH void rgtc_signed_prepare() {}
+DH const RgtcSignedTables &rgtc_signed() { return kRgtcSignedTables; }
+#endif
+// 16-bit entry at a BYTE offset (offsets are built pre-doubled so that no shift is needed)
+DH uint32_t u16_at(const uint16_t *table, uint32_t byte_offset) {
+	return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(table) + byte_offset);
+}
+
 DH bool rgtc_channel_s16(uint32_t w0, uint32_t w1, uint32_t (&pairs)[8]) {
 	int32_t e0 = sbfe(w0, 0, 8), e1 = sbfe(w0, 8, 8);
 	const bool valid = !(e0 == -127 && e1 == -128);		// :90-92
 	e0 = max(e0, -127);
 	e1 = max(e1, -127);
 	const uint32_t seven = cond_to_mask(e0 > e1);
-	const int32_t step = e1 - e0;
+	const RgtcSignedTables &t = rgtc_signed();
+	// byte offsets 2*(x + bias): base 2*d*e0 + 2*bias, step 2*(e1 - e0) per k -- all non-negative
+	const uint32_t step2 = (uint32_t)(2 * (e1 - e0));
+	const uint32_t base7 = (uint32_t)(14 * e0 + 2 * 896), base5 = (uint32_t)(10 * e0 + 2 * 640);
 	uint32_t w[8];						// the eight ramp entries as unsigned 16-bit (sign bit still flipped)
-	w[0] = rgtc_biased_to_u16((uint32_t)(e0 + 127));
-	w[1] = rgtc_biased_to_u16((uint32_t)(e1 + 127));
+	w[0] = u16_at(t.map, (uint32_t)(2 * e0 + 254));
+	w[1] = u16_at(t.map, (uint32_t)(2 * e1 + 254));
 #pragma unroll
 	for (int k = 1; k <= 6; k++) {
-		const int32_t x7 = 7 * e0 + k * step;		// (7-k)*e0 + k*e1
-		const uint32_t u7 = div7_u((uint32_t)(x7 + 896 + ((x7 >> 31) & 6)));	// trunc(x7/7) + 128
-		uint32_t u5;
-		if (k <= 4) {
-			const int32_t x5 = 5 * e0 + k * step;
-			u5 = div5_u((uint32_t)(x5 + 640 + ((x5 >> 31) & 4)));		// trunc(x5/5) + 128
-		} else {
-			u5 = k == 5 ? 1u : 255u;					// -127 and 127
-		}
-		w[1 + k] = rgtc_biased_to_u16(bfi(seven, u7, u5) - 1u);
+		const uint32_t w7 = u16_at(t.t7, base7 + (uint32_t)k * step2);
+		const uint32_t w5 = k <= 4 ? u16_at(t.t5, base5 + (uint32_t)k * step2)
+			: (k == 5 ? rgtc_map16_flipped(-127) : rgtc_map16_flipped(127));	// entries 6, 7 of the five-ramp: -1.0 and 1.0
+		w[1 + k] = bfi(seven, w7, w5);
 	}
 	// low-byte and high-byte tables of the eight entries for v_perm lookups
 	const uint32_t p01 = perm(w[1], w[0], 0x05010400u), p23 = perm(w[3], w[2], 0x05010400u);	// {lo a, lo b, hi a, hi b}
@@ -211,6 +244,7 @@ struct DecRGTC2 {
 };
 
 struct DecSignedRGTC1 {
+	static DH void prepare() { rgtc_signed_prepare(); }
 	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return rgtc_channel_s16(blk.x, blk.y, d);
@@ -218,6 +252,7 @@ struct DecSignedRGTC1 {
 };
 
 struct DecSignedRGTC2 {
+	static DH void prepare() { rgtc_signed_prepare(); }
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
 	// decompress-rgtc.c:141-147: texel = R16 | G16 << 16
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {
