@@ -3,11 +3,16 @@
 // The reference decodes with an 8-way mode switch, a bit-at-a-time 128-bit reader and per-texel
 // table lookups (decompress-bptc.c:354-512).  A wavefront of 64 independent blocks would execute
 // every taken mode path serially, so this decoder is a single DIVERGENCE-FREE data-driven path:
-// the per-mode layout (subsets, field widths, P-bit kind, index widths) is one packed descriptor
-// word fetched from __constant__ memory by the lane's mode, every field position is computed
-// arithmetically, fields are pulled out of the 128-bit block with funnel shifts, endpoints are
-// expanded to 8 bits with SWAR byte math and texels are blended two channels per multiply.
-// Partition / anchor tables are the bit-packed words of bptc_tables.inc in __constant__ memory.
+//   * everything about a mode that does not depend on the block (field positions and widths, expansion
+//     shifts, index widths, weight constants) is a Bc7Layout record derived at compile time from the
+//     eight mode descriptors and fetched per lane from a workgroup LDS copy;
+//   * the block's bits and the (up to three) subsets' blend operands live in per-lane LDS rows
+//     (dev_common.h: LaneRows), so a field is two dwords + v_alignbit_b32 and a texel's subset is one
+//     ds_read_b128 instead of register-select chains;
+//   * endpoints are expanded to 8 bits with SWAR byte math, the two index streams are read through two
+//     32-bit windows each (one shift per texel), a weight is one v_mad_u32_u24, and a texel is blended two
+//     channels per v_pk_mad_u16.
+// Partition / anchor tables are the bit-packed words of bptc_tables.inc (__constant__, LDS copy per workgroup).
 //
 // Reference quirk reproduced: in mode 6 the second P-bit (block bit 64) reads 0.
 #pragma once
