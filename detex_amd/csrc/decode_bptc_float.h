@@ -1,11 +1,13 @@
 // decode_bptc_float.h -- BPTC_FLOAT (BC6H), unsigned and signed, 14 modes, one lane per block.
 //
-// Structure: the only genuinely mode-specific step is the scatter of the endpoint bits, so that
-// alone is a 14-way switch whose cases are generated AT COMPILE TIME from the bit-layout strings
-// of the BPTC specification (constexpr parser -> per-field v_bfe_u32 / v_alignbit_b32 with
-// literal positions).  Everything after it -- sign extension, delta transform, unquantisation,
-// partition/anchor lookup, index extraction, interpolation, half-float finish -- is one shared
-// branch-free path driven by four per-lane parameters (endpoint bits, three delta widths).
+// Structure: the only genuinely mode-specific step is the scatter of the endpoint bits.  The bit-layout strings
+// of the BPTC specification are parsed AT COMPILE TIME (constexpr) into (a) per-mode descriptor words for the
+// default divergence-free scatter -- every main field sits at one of a few canonical positions with a per-mode
+// width, the 15 "loose" bits are routed by 5-bit source indices -- and (b) a 14-way switch with literal
+// positions, kept as the A/B alternative (SWITCH_SCATTER).  Everything after it -- sign extension, delta
+// transform, unquantisation, partition/anchor lookup, index extraction (two 32-bit windows), interpolation
+// from per-lane LDS rows of base/diff values, half-float finish (packed 16-bit lanes for the signed
+// sign-magnitude form) -- is one shared branch-free path driven by four per-lane parameters.
 // All arithmetic is integer; the output is raw IEEE half bit patterns with X = 0
 // (DETEX_PIXEL_FORMAT_FLOAT_RGBX16 / SIGNED_FLOAT_RGBX16).
 //

@@ -3,9 +3,12 @@
 // One lane = one block.  The colour codec is restructured around per-sub-block 4-entry
 // palettes of packed RGBA dwords: individual/differential blocks, T blocks and H blocks all
 // reduce to "texel = palette[sub-block][2-bit selector]", so they share one branch-free texel
-// loop (v_bfe_i32 lane masks + v_bfi_b32); only planar blocks take a separate path.  The
-// selector planes are big-endian and texels are numbered column-major.
-// Format tables live in __constant__ memory / literal operands (north_star).
+// loop (v_bfe_i32 lane masks + v_bitop3_b32 selects); T and H are first reduced to two 12-bit colours
+// and a distance and share their arithmetic; only planar blocks take a separate path (row / column
+// increments).  Colour arithmetic runs two signed 16-bit lanes per VGPR with the saturating pack
+// v_sat_pk_u8_i16 as the 0..255 clamp.  The selector planes are big-endian and texels are numbered
+// column-major.  ETC tables are literal operands (v_perm_b32 pools); the EAC modifier
+// table lives in __constant__ memory with a workgroup LDS copy (north_star).
 #pragma once
 #include "dev_common.h"
 #include "decode_s3tc_rgtc.h"

@@ -3,8 +3,9 @@
 // One lane decodes one 4x4 block into registers, row-major, as dwords d[row*P + k]
 // (P = bytes per pixel = dwords per 4-pixel row).  Behaviour follows the reference decoders
 // cited per function (/root/reference); the code structure does not: palettes are built as
-// packed RGBA dwords and texels are picked with lane masks (v_bfe_i32 + v_bfi_b32) or byte
-// permutes (v_perm_b32) instead of per-texel switch statements and division LUTs.
+// packed RGBA dwords and texels are picked with lane masks (v_bfe_i32 + v_bitop3_b32) or byte
+// permutes (v_perm_b32) instead of per-texel switch statements; divisions are multiply-shifts, except
+// the signed RGTC ramp, whose entries are single lookups in compile-time tables (LDS copy per workgroup).
 #pragma once
 #include "dev_common.h"
 
