@@ -15,7 +15,7 @@ echo "== epilogue targets"; for t in BGRA8 RGB8; do timeout 200 python bench.py 
 echo "== BC6H A/B: switch scatter (variant 3), cached stores (variant 2)"; for v in 0 2 3; do timeout 200 python bench.py --format BPTC_FLOAT --variant $v --steps 200 --warmup 400 --no-cpu > $OUT/bench_bc6h_v$v.json 2>>$OUT/bench.err; python -c "import json;d=json.load(open('$OUT/bench_bc6h_v$v.json'));print('BPTC_FLOAT variant $v', d['roofline']['launch_us'], 'us', d['roofline']['frac'])"; done
 echo "== BC7 A/B: 3 = register-select texel stage, 4 = register field extraction, 5 = mode-sorted waves"; for v in 0 3 4 5; do timeout 200 python bench.py --format BPTC --variant $v --steps 200 --warmup 400 --no-cpu > $OUT/bench_bc7_v$v.json 2>>$OUT/bench.err; python -c "import json;d=json.load(open('$OUT/bench_bc7_v$v.json'));print('BPTC variant $v', d['roofline']['launch_us'], 'us', d['roofline']['frac'], d.get('verified_bit_exact_rows'))"; done
 echo "== block-major (tiled) layout"; for f in BC1 BPTC BPTC_FLOAT RGTC2; do timeout 200 python bench.py --format $f --layout tiled --steps 200 --warmup 400 --no-cpu > $OUT/bench_tiled_$f.json 2>>$OUT/bench.err; python -c "import json;d=json.load(open('$OUT/bench_tiled_$f.json'));print('$f tiled', d['roofline']['launch_us'], 'us', d['roofline']['frac'], d.get('verified_bit_exact_rows'))"; done
-echo "== 32768-wide bands (the sharded 32768^2 configs: one GPU's band)"; timeout 300 python bench.py --format BPTC_FLOAT --size 32768 --band-height 4096 --steps 20 --no-cpu > $OUT/bench_bc6h_32768x4096.json 2>>$OUT/bench.err; timeout 300 python bench.py --size 32768 --band-height 8192 --steps 20 --no-cpu > $OUT/bench_bc1_32768x8192.json 2>>$OUT/bench.err; for f in bench_bc6h_32768x4096 bench_bc1_32768x8192; do python -c "import json;d=json.load(open('$OUT/$f.json'));print('$f', d['value'], 'Gpixel/s', d['roofline']['launch_us'], 'us', d['roofline']['frac'])"; done
+echo "== 32768-wide bands (the sharded 32768^2 configs: one GPU's band)"; timeout 300 python bench.py --format BPTC_FLOAT --size 32768 --band-height 4096 --steps 100 --warmup 300 --no-cpu > $OUT/bench_bc6h_32768x4096.json 2>>$OUT/bench.err; timeout 300 python bench.py --size 32768 --band-height 8192 --steps 20 --no-cpu > $OUT/bench_bc1_32768x8192.json 2>>$OUT/bench.err; for f in bench_bc6h_32768x4096 bench_bc1_32768x8192; do python -c "import json;d=json.load(open('$OUT/$f.json'));print('$f', d['value'], 'Gpixel/s', d['roofline']['launch_us'], 'us', d['roofline']['frac'])"; done
 echo "== per-format table"; timeout 900 python bench.py --steps 80 --no-cpu --formats-json $OUT/formats_8192.json > /dev/null 2> $OUT/formats.err; grep launch_us $OUT/formats.err
 echo "== launch time per 25-launch window (power-management transient of VALU-heavy kernels)"; for f in BC1 ETC2 BPTC BPTC_FLOAT; do timeout 120 python tools/gpu_sustain.py $f 32 2>&1 | tail -2; done | tee $OUT/sustain_windows.txt
 echo "== mip chains: per-level launches vs one launch"; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cat $OUT/mips.json
