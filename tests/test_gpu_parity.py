@@ -372,6 +372,29 @@ def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), want_l)
 
 
+def test_empty_inputs(hiplib, torch_cuda):
+    """empty textures / zero blocks: the reference's loops simply do not run (texture.c:111-144 -> true, nothing
+    written); no launch with an empty grid, no error text"""
+    from detex_amd import binding
+    torch = torch_cuda
+    for name in ("BC1", "BPTC", "BPTC_FLOAT", "RGTC1"):
+        fmt = F.BY_NAME[name]
+        for (w, h) in ((0, 0), (0, 8), (8, 0)):
+            out = np.full(64, 0xA5, np.uint8)
+            tex = hiplib._texture(fmt, np.zeros(16, np.uint8), w, h)
+            import ctypes
+            assert hiplib.lib.detexDecompressTextureLinear(ctypes.byref(tex), ol._ptr(out), F.native_pixel_format(fmt))
+            assert hiplib.lib.detexDecompressTextureTiled(ctypes.byref(tex), ol._ptr(out), F.native_pixel_format(fmt))
+            assert (out == 0xA5).all()
+        canvas = torch.full((256,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        binding.decompress_linear_device(fmt, canvas[:16], 0, 0, out=canvas, status=status)
+        binding.decompress_tiled_device(fmt, canvas[:16], 0, 0, out=canvas, status=status)
+        binding.decompress_blocks_device(fmt, canvas[:16], 0, out=canvas)
+        torch.cuda.synchronize()
+        assert (canvas.cpu().numpy() == 0xA5).all() and status.item() == 0
+
+
 def test_device_tier_is_graph_capturable(torch_cuda, oracle):
     """a device-tier call is one asynchronous launch with no allocation or synchronisation inside, so it
     can be captured into a hipGraph: capture three decodes (linear, tiled, mip levels via separate calls), replay twice
