@@ -128,3 +128,15 @@ def decompress_blocks_device(fmt, blocks, n_blocks, mode_mask=F.MODE_MASK_ALL, f
         fmt.texture_format, blocks.data_ptr(), n_blocks, mode_mask, flags, out.data_ptr(), ok.data_ptr(),
         _stream_handle(stream)), "detexhipDecompressBlocksDevice")
     return out, ok
+
+
+def mode_histogram_device(fmt, blocks, n_blocks, hist=None, stream=None):
+    """detexhipModeHistogramDevice: 16 bins (uint32) of the reference's detexGetMode<FMT> values."""
+    import torch
+    lib = load()
+    if hist is None:
+        hist = torch.zeros(16, dtype=torch.int32, device=blocks.device)
+    lib.detexhipModeHistogramDevice.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib.detexhipModeHistogramDevice(fmt.texture_format, blocks.data_ptr(), n_blocks, hist.data_ptr(), _stream_handle(stream)),
+           "detexhipModeHistogramDevice")
+    return hist

@@ -91,23 +91,38 @@ template <int CLASS> DH uint32_t block_mode(const uint32_t *w) {	// w = the bloc
 	} else return 0u;
 }
 
-// Persistent grid-stride kernel: per-wave ballots -> LDS counters -> 16 atomics per workgroup.
+// Persistent grid-stride kernel: per-wave ballots -> LDS counters -> 16 atomics per workgroup.  Four blocks per
+// lane per trip, all four loads issued before the first is classified: the kernel only reads, so its speed is
+// the number of bytes it keeps in flight (one load per trip measured 1.9 TB/s on 8192^2 BC7).
 template <int CLASS, int BLOCK_DWORDS>
 __global__ __launch_bounds__(256) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
 		uint32_t *__restrict__ hist) {
+	typedef typename BlockWord<4 * BLOCK_DWORDS>::type Word;
+	constexpr int UNROLL = 4;
 	__shared__ uint32_t bins[16];
 	if (threadIdx.x < 16) bins[threadIdx.x] = 0;
 	__syncthreads();
 	uint32_t local[16];
 #pragma unroll
 	for (int m = 0; m < 16; m++) local[m] = 0;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_blocks; i += gridDim.x * 256u) {
-		uint32_t w[BLOCK_DWORDS];
-		if constexpr (BLOCK_DWORDS == 2) { const uint2 v = reinterpret_cast<const uint2 *>(blocks)[i]; w[0] = v.x; w[1] = v.y; }
-		else { const uint4 v = reinterpret_cast<const uint4 *>(blocks)[i]; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-		const uint32_t mode = block_mode<CLASS>(w);
+	const uint32_t stride = gridDim.x * 256u;
+	for (uint64_t i = blockIdx.x * 256u + threadIdx.x; i < n_blocks; i += (uint64_t)stride * UNROLL) {	// 64-bit: n_blocks may be close to 2^32
+		Word v[UNROLL];
+		bool live[UNROLL];
 #pragma unroll
-		for (int m = 0; m < 16; m++) local[m] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mode == (uint32_t)m));
+		for (int k = 0; k < UNROLL; k++) {
+			const uint64_t j = i + (uint64_t)k * stride;
+			live[k] = j < n_blocks;
+			v[k] = live[k] ? reinterpret_cast<const Word *>(blocks)[j] : Word{};
+		}
+#pragma unroll
+		for (int k = 0; k < UNROLL; k++) {
+			uint32_t w[BLOCK_DWORDS];
+			__builtin_memcpy(w, &v[k], sizeof w);
+			const uint32_t mode = live[k] ? block_mode<CLASS>(w) : 0xFFFFFFFFu;
+#pragma unroll
+			for (int m = 0; m < 16; m++) local[m] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mode == (uint32_t)m));
+		}
 	}
 	if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
