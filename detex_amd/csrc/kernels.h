@@ -121,10 +121,12 @@ DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t
 
 // 64-bit pixels: a lane's texel row is 32 B, so a plain dwordx4 store writes 16 of every 32 bytes and the
 // line is completed by the NEXT instruction -- measured 2.5 TB/s for streaming stores (BC6H 217 us).  Each row
-// is transposed through 2 KiB of LDS per wave so that every store instruction covers one contiguous 1 KiB
-// run, as for the 32-bit formats.  Needs the wave's 64 blocks in one block row (width_in_blocks % 64 == 0;
-// then every wave is also full).  dst = this lane's block in image row 4*by.
-DH void store_rows_wide_pixels(uint8_t *dst, uint64_t pitch, const uint32_t (&o)[32]) {
+// is transposed through LDS (2.1 KiB per wave) so that every store instruction covers contiguous 1 KiB runs,
+// as for the 32-bit formats.  Works for any width: output vector e of the wave belongs to block first + e/2,
+// whose place in the image is recomputed by the storing lane (a wave that straddles the end of a block row
+// simply continues on the next one); every lane of the wave must call this, `live` or not.
+DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks,
+		bool live, const uint32_t (&o)[32]) {
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	// [half of the lane's 32-byte row][lane], the second half 72 vectors on: writes (consecutive lanes) and
 	// transposed reads (output vector e = 2*lane' + half) are both bank-conflict free
@@ -132,12 +134,20 @@ DH void store_rows_wide_pixels(uint8_t *dst, uint64_t pitch, const uint32_t (&o)
 	__shared__ v4 xpose[4][STRIDE + 64];
 	v4 *slab = xpose[threadIdx.x >> 6];
 	const uint32_t lane = threadIdx.x & 63u;
-	uint8_t *row0 = dst - (uint64_t)lane * 32u;		// start of the wave's 2 KiB row segment
 	const uint32_t src_a = (lane & 1u) * STRIDE + (lane >> 1), src_b = src_a + 32u;	// vectors e = lane and e = 64 + lane
+	// destinations of those two vectors: blocks first + lane/2 and first + 32 + lane/2
+	const uint32_t ia = first + (lane >> 1), ib = ia + 32u;
+	uint32_t by, bx;
+	split_index(ia, width_in_blocks, by, bx);
+	uint8_t *dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+	split_index(ib, width_in_blocks, by, bx);
+	uint8_t *dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
-		slab[lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
-		slab[STRIDE + lane] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+		if (live) {
+			slab[lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
+			slab[STRIDE + lane] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+		}
 		// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
 		// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -146,9 +156,8 @@ DH void store_rows_wide_pixels(uint8_t *dst, uint64_t pitch, const uint32_t (&o)
 		const v4 a = slab[src_a], b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		v4 *out = reinterpret_cast<v4 *>(row0 + (uint64_t)r * pitch);
-		__builtin_nontemporal_store(a, out + lane);
-		__builtin_nontemporal_store(b, out + 64 + lane);
+		if (ia < n_blocks) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a + (uint64_t)r * pitch));
+		if (ib < n_blocks) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b + (uint64_t)r * pitch));
 	}
 }
 
@@ -177,19 +186,22 @@ __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ bl
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
 	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if constexpr (ROW == 8 && NT) {
+		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
+		const bool live = i < n_blocks;
+		uint32_t o[4 * ROW];
+		bool ok = true;
+		if (live) ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+		store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
+		if (live) raise_status(!ok, status);
+		return;
+	}
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
 	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
 	uint32_t by, bx;
 	split_index(i, width_in_blocks, by, bx);
 	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
-	if constexpr (ROW == 8 && NT) {
-		if ((width_in_blocks & 63u) == 0u) {
-			store_rows_wide_pixels(dst, pitch, o);
-			raise_status(!ok, status);
-			return;
-		}
-	}
 #pragma unroll
 	for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
 	raise_status(!ok, status);

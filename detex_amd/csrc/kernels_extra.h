@@ -34,6 +34,17 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	for (uint32_t k = 1; k < table.n_levels; k++) l = blockIdx.x >= table.wg_start[k] ? k : l;
 	const LevelDesc &lv = table.level[l];
 	const uint32_t i = (blockIdx.x - table.wg_start[l]) * 256u + threadIdx.x;
+	if constexpr (ROW == 8) {
+		if (lv.fast) {		// workgroup-uniform (a workgroup never spans two levels): 64-bit pixels leave through the LDS transpose
+			const bool live = i < lv.n_blocks;
+			uint32_t o[4 * ROW];
+			bool ok = true;
+			if (live) ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
+			store_rows_wide_pixels(lv.pixels, lv.pitch, lv.width_in_blocks, i - (threadIdx.x & 63u), lv.n_blocks, live, o);
+			if (live) raise_status(!ok, status);
+			return;
+		}
+	}
 	if (i >= lv.n_blocks) return;
 	uint32_t o[4 * ROW];
 	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
@@ -41,13 +52,6 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	split_index(i, lv.width_in_blocks, by, bx);
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
 	if (lv.fast) {
-		if constexpr (ROW == 8) {
-			if ((lv.width_in_blocks & 63u) == 0u) {		// workgroup-uniform: a workgroup never spans two levels
-				store_rows_wide_pixels(dst, lv.pitch, o);
-				raise_status(!ok, status);
-				return;
-			}
-		}
 #pragma unroll
 		for (int r = 0; r < 4; r++) store_row<ROW, true>(dst + (uint64_t)r * lv.pitch, o + r * ROW);
 	} else {
