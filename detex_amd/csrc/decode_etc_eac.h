@@ -238,12 +238,6 @@ DH EacWord eac_word(uint32_t w0, uint32_t w1) {
 	return e;
 }
 DH uint32_t eac_selector(const EacWord &e, int p) { return ubfe(p < 8 ? e.sel_a : e.sel_b, 21 - 3 * (p & 7), 3); }
-// modifier of selector s: s<4 -> -m[s], s>=4 -> m[s&3]-1
-DH int32_t eac_modifier(uint32_t row, int s) {
-	const int32_t m = (int32_t)ubfe(row, 4 * (s & 3), 4);
-	return (s & 4) ? m - 1 : -m;
-}
-
 // ETC2_EAC alpha plane (decompress-eac.c:54-86): alpha = clamp255(base + modifier * multiplier),
 // multiplier 0 allowed (A-8).  Builds the 8-entry alpha table once, then one v_perm per texel.
 DH void eac_alpha_overlay(uint32_t w0, uint32_t w1, uint32_t (&d)[16]) {
@@ -266,25 +260,30 @@ DH void eac_alpha_overlay(uint32_t w0, uint32_t w1, uint32_t (&d)[16]) {
 // unsigned: decompress-eac.c:111-128; signed: :159-201 (base -128 is invalid, A-5).
 template <bool SIGNED> DH bool eac11_channel(uint32_t w0, uint32_t w1, uint32_t (&pairs)[8]) {
 	const EacWord e = eac_word(w0, w1);
-	const int32_t mult8 = e.mult ? (int32_t)e.mult * 8 : 1;
-	const int32_t base = SIGNED ? (int32_t)(int8_t)e.base * 8 : (int32_t)e.base * 8 + 4;
-	uint32_t lo_l = 0, lo_h = 0, hi_l = 0, hi_h = 0;	// low-byte / high-byte tables of the 8 possible values
+	// the eight table values, two per VGPR in signed 16-bit lanes: raw = base - m*mult8 (selectors 0-3) and
+	// base + (m-1)*mult8 (4-7); |raw| <= 2044 + 15*120 fits, and so does every later step
+	const uint32_t mult8 = e.mult ? e.mult * 8u : 1u;
+	const uint32_t base = SIGNED ? (uint32_t)(sbfe(e.base, 0, 8) * 8) & 0xFFFFu : e.base * 8u + 4u;
+	const uint32_t mult2 = pack16(mult8, mult8), base2 = pack16(base, base), bm = pk_sub16(base2, mult2);
+	const uint32_t m01 = (e.row & 0xFu) | ((e.row << 12) & 0xF0000u), m23 = ((e.row >> 8) & 0xFu) | ((e.row << 4) & 0xF0000u);
+	const uint32_t mm01 = pk_mul16(m01, mult2), mm23 = pk_mul16(m23, mult2);
+	uint32_t t[4] = { pk_sub16(base2, mm01), pk_sub16(base2, mm23), pk_add16(bm, mm01), pk_add16(bm, mm23) };
 #pragma unroll
-	for (int s = 0; s < 8; s++) {
-		const int32_t raw = base + eac_modifier(e.row, s) * mult8;
-		uint32_t v16;
-		if (SIGNED) {
-			const int32_t v = clampi(raw, -1023, 1023);
-			const int32_t m = v < 0 ? -v : v;
-			const int32_t wide = (m << 5) | (m >> 5);
-			v16 = (uint32_t)(v < 0 ? -wide : wide) & 0xFFFFu;
-		} else {
-			const uint32_t v = (uint32_t)clampi(raw, 0, 2047);
-			v16 = (v << 5) | (v >> 6);
+	for (int k = 0; k < 4; k++) {
+		if (SIGNED) {		// :159-201: clamp to +-1023, 11-bit magnitude widened to 16 bits by bit replication, sign restored
+			const uint32_t v = pk_min16(pk_max16(t[k], 0xFC01FC01u), 0x03FF03FFu);
+			const uint32_t m = pk_max16(v, pk_sub16(0u, v));
+			const uint32_t wide = pk_lshl16(m, 5) | pk_lshr16(m, 5);
+			const uint32_t sg = pk_ashr16(v, 15);
+			t[k] = pk_sub16(wide ^ sg, sg);
+		} else {		// :111-128: clamp to 0..2047, widen by bit replication
+			const uint32_t v = pk_min16(pk_max16(t[k], 0u), 0x07FF07FFu);
+			t[k] = pk_lshl16(v, 5) | pk_lshr16(v, 6);
 		}
-		if (s < 4) { lo_l |= (v16 & 0xFFu) << (8 * s); hi_l |= (v16 >> 8) << (8 * s); }
-		else { lo_h |= (v16 & 0xFFu) << (8 * (s - 4)); hi_h |= (v16 >> 8) << (8 * (s - 4)); }
 	}
+	// low-byte / high-byte tables of the 8 values for v_perm lookups
+	const uint32_t lo_l = perm(t[1], t[0], 0x06040200u), hi_l = perm(t[1], t[0], 0x07050301u);
+	const uint32_t lo_h = perm(t[3], t[2], 0x06040200u), hi_h = perm(t[3], t[2], 0x07050301u);
 #pragma unroll
 	for (int y = 0; y < 4; y++) {
 		// row y holds column-major texels p = 4x + y
@@ -294,7 +293,7 @@ template <bool SIGNED> DH bool eac11_channel(uint32_t w0, uint32_t w1, uint32_t 
 		pairs[2 * y] = perm(h4, l4, 0x05010400u);
 		pairs[2 * y + 1] = perm(h4, l4, 0x07030602u);
 	}
-	return !SIGNED || (int8_t)e.base != -128;
+	return !SIGNED || (e.base & 0xFFu) != 0x80u;
 }
 
 struct DecETC1 {

@@ -107,6 +107,8 @@ DH uint32_t pk_sub16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) - t
 DH uint32_t pk_ashr16(uint32_t a, int s) { return of_pk_i16(to_pk_i16(a) >> (int16_t)s); }
 DH uint32_t pk_mul16(uint32_t a, uint32_t b) { return of_pk_i16(to_pk_i16(a) * to_pk_i16(b)); }
 DH uint32_t pk_max16(uint32_t a, uint32_t b) { return of_pk_i16(__builtin_elementwise_max(to_pk_i16(a), to_pk_i16(b))); }	// signed
+DH uint32_t pk_min16(uint32_t a, uint32_t b) { return of_pk_i16(__builtin_elementwise_min(to_pk_i16(a), to_pk_i16(b))); }	// signed
+DH uint32_t pk_lshl16(uint32_t a, int s) { return of_pk_i16(to_pk_i16(a) << (int16_t)s); }
 typedef uint16_t pk_u16 __attribute__((ext_vector_type(2)));
 DH uint32_t pk_lshr16(uint32_t a, int s) { pk_u16 v; __builtin_memcpy(&v, &a, 4); v = v >> (uint16_t)s; uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
 // both signed 16-bit lanes clamped to 0..255: lane 0 -> byte 0, lane 1 -> byte 1.  Only bytes 0
@@ -124,6 +126,11 @@ DH uint32_t pk_max16(uint32_t a, uint32_t b) {
 	return ((uint32_t)max(al, bl) & 0xFFFFu) | ((uint32_t)max(ah, bh) << 16);
 }
 DH uint32_t pk_lshr16(uint32_t a, int s) { return ((a & 0xFFFFu) >> s) | (((a >> 16) >> s) << 16); }
+DH uint32_t pk_min16(uint32_t a, uint32_t b) {
+	const int32_t al = (int16_t)(a & 0xFFFFu), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xFFFFu), bh = (int16_t)(b >> 16);
+	return ((uint32_t)min(al, bl) & 0xFFFFu) | ((uint32_t)min(ah, bh) << 16);
+}
+DH uint32_t pk_lshl16(uint32_t a, int s) { return ((a << s) & 0xFFFFu) | ((((a >> 16) << s) & 0xFFFFu) << 16); }
 DH uint32_t sat_u8_pk16(uint32_t a) {
 	const int32_t lo = (int16_t)(a & 0xFFFFu), hi = (int16_t)(a >> 16);
 	return (uint32_t)clampi(lo, 0, 255) | ((uint32_t)clampi(hi, 0, 255) << 8) | 0xDEAD0000u;	// poison the unspecified half
