@@ -1,0 +1,16 @@
+"""Reference points for the HBM roofline on this box: what plain fill / copy kernels of the same footprint reach.
+(bytes moved per second; copy counts read + write)"""
+import torch
+def t(fn, n=50):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+for mib in (256, 1024):
+    nbytes = mib << 20
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda"); b = torch.empty_like(a)
+    s = t(lambda: a.fill_(7)); print("fill  %4d MiB: %7.1f us  %.2f TB/s written" % (mib, s * 1e6, nbytes / s / 1e12))
+    s = t(lambda: torch.cuda.memset if False else a.zero_()); print("zero  %4d MiB: %7.1f us  %.2f TB/s written" % (mib, s * 1e6, nbytes / s / 1e12))
+    s = t(lambda: b.copy_(a)); print("copy  %4d MiB: %7.1f us  %.2f TB/s read+written" % (mib, s * 1e6, 2 * nbytes / s / 1e12))

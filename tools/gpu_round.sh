@@ -19,6 +19,7 @@ echo "== 32768-wide bands (the sharded 32768^2 configs: one GPU's band)"; timeou
 echo "== per-format table"; timeout 900 python bench.py --steps 80 --no-cpu --formats-json $OUT/formats_8192.json > /dev/null 2> $OUT/formats.err; grep launch_us $OUT/formats.err
 echo "== launch time per 25-launch window (power-management transient of VALU-heavy kernels)"; for f in BC1 ETC2 BPTC BPTC_FLOAT; do timeout 120 python tools/gpu_sustain.py $f 32 2>&1 | tail -2; done | tee $OUT/sustain_windows.txt
 echo "== mip chains: per-level launches vs one launch"; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cat $OUT/mips.json
+echo "== HBM reference (plain fill / copy)"; timeout 200 python tools/gpu_hbm_ref.py 2>/dev/null | tee $OUT/hbm_reference.txt
 echo "== mode histograms"; timeout 300 python tools/bench_histogram.py 2>/dev/null | tee $OUT/histogram.txt
 echo "== VALU instruction rates"; [ -x tools/ubench/valu_rates ] && ./tools/ubench/valu_rates > $OUT/valu_rates.txt 2>&1; cat $OUT/valu_rates.txt
 echo "== rocprofv3 kernel trace"

@@ -10,5 +10,5 @@ for fmt in BPTC BPTC_FLOAT; do f=$SRC/prof_sq_$fmt/sq_counter_collection.csv; [ 
 cp $SRC/formats_8192.json $SRC/bench.json $SRC/bench_v1.json $SRC/bench_v2.json $SRC/bench_16384.json $SRC/bench_bc1_BGRA8.json $SRC/bench_bc1_RGB8.json \
    $SRC/bench_bc6h_v0.json $SRC/bench_bc6h_v2.json $SRC/bench_bc6h_v3.json $SRC/bench_bc6h_32768x4096.json $SRC/bench_bc1_32768x8192.json \
    $SRC/bench_bc7_v0.json $SRC/bench_bc7_v3.json $SRC/bench_bc7_v4.json $SRC/bench_bc7_v5.json $SRC/bench_tiled_BC1.json $SRC/bench_tiled_BPTC.json $SRC/bench_tiled_BPTC_FLOAT.json $SRC/bench_tiled_RGTC2.json \
-   $SRC/sustain_windows.txt $SRC/histogram.txt $SRC/mips.json $SRC/valu_rates.txt $SRC/pytest_gpu.log $SRC/round.log $DST/ 2>/dev/null
+   $SRC/sustain_windows.txt $SRC/histogram.txt $SRC/hbm_reference.txt $SRC/mips.json $SRC/valu_rates.txt $SRC/pytest_gpu.log $SRC/round.log $DST/ 2>/dev/null
 ls $DST
