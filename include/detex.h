@@ -9,9 +9,11 @@
  * this header exists so that the repo is self-contained on machines without the reference.
  *
  * Each declaration cites the reference interface it replaces (file:line in /root/reference).
- * Everything of the reference API that is NOT listed here (file I/O, pixel conversion beyond
- * the identity / RGBX8<->RGBA8 no-op edge, HDR, encoder helpers) is out of scope (SURVEY.md
- * section 8) and is not exported.
+ * Everything of the reference API that is NOT listed here (DDS / raw / PNG I/O, KTX saving,
+ * detexConvertPixels as a stand-alone call, HDR, encoder helpers) is out of scope (SURVEY.md
+ * section 8) and is not exported.  Target pixel formats accepted by the decode entry points:
+ * the native one, RGBX8 <-> RGBA8, and -- converted inside the kernel with detexConvertPixels'
+ * semantics (convert.c:37-70, 671-684) -- BGRA8, BGRX8, RGB8 and FLOAT_BGRX16 (constants below).
  */
 #ifndef DETEXHIP_COMPAT_DETEX_H
 #define DETEXHIP_COMPAT_DETEX_H
@@ -39,6 +41,10 @@ enum {
 	DETEX_PIXEL_FORMAT_SIGNED_RG16 = 0x1311,
 	DETEX_PIXEL_FORMAT_RGBX8 = 0x0320,
 	DETEX_PIXEL_FORMAT_RGBA8 = 0x0334,
+	DETEX_PIXEL_FORMAT_RGB8 = 0x0220,		/* in-kernel epilogue targets */
+	DETEX_PIXEL_FORMAT_BGRX8 = 0x0328,
+	DETEX_PIXEL_FORMAT_BGRA8 = 0x033C,
+	DETEX_PIXEL_FORMAT_FLOAT_BGRX16 = 0x2729,
 	DETEX_PIXEL_FORMAT_FLOAT_RGBX16 = 0x2721,
 	DETEX_PIXEL_FORMAT_SIGNED_FLOAT_RGBX16 = 0x3721,
 };
