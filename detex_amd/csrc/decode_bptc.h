@@ -218,9 +218,14 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		const uint32_t c_up = L.c_up, c_down = L.c_down, c_keep = L.c_keep, a_up = L.a_up, a_down = L.a_down;
 		// P-bit of endpoint e at bit e: per-endpoint P-bits as stored, a shared P-bit (mode 1) doubled
 		const uint32_t pw_e = bfi(L.p_double, ((pw & 1u) * 3u) | ((pw & 2u) * 6u), pw) & (0u - has_p);
-		uint32_t ep[6];
+		// subsets actually present in this wave (wave-uniform): endpoints of absent subsets are not expanded.  The
+		// uniform-random stream always has three-subset blocks (modes 0, 2) in every wave; encoder output mostly does not.
+		const uint32_t wave_subsets = FIXED_MODE >= 0 ? L.ns : (IMPL == 0 ? 3u
+			: (__builtin_amdgcn_ballot_w64(ns == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(ns == 2u) ? 2u : 1u)));
+		uint32_t ep[6] = {};
 #pragma unroll
 		for (int e = 0; e < 6; e++) {
+			if ((uint32_t)(e >> 1) >= wave_subsets) break;
 			const uint32_t off = L.off[e];
 			// (three-input logic goes through v_bitop3_b32 -- dev_common.h: and_or / or3 -- at 2.5 cycles instead of 4.4)
 			uint32_t x = or3(ubfe(wr, off, cb), ubfe(wg, off, cb) << 8, ubfe(wb, off, cb) << 16);
@@ -288,6 +293,7 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		LaneRows<uint4, 3, 72> subsets;
 #pragma unroll
 		for (int s = 0; s < 3; s++) {
+			if ((uint32_t)s >= wave_subsets) break;
 			const uint32_t e0 = ep[2 * s], e1 = ep[2 * s + 1];
 			const uint32_t rg0 = perm(0u, e0, 0x0C010C00u), ba0 = perm(0u, e0, 0x0C030C02u);
 			const uint32_t rg1 = perm(0u, e1, 0x0C010C00u), ba1 = perm(0u, e1, 0x0C030C02u);
