@@ -222,6 +222,8 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 		// uniform-random stream always has three-subset blocks (modes 0, 2) in every wave; encoder output mostly does not.
 		const uint32_t wave_subsets = FIXED_MODE >= 0 ? L.ns : (IMPL == 0 ? 3u
 			: (__builtin_amdgcn_ballot_w64(ns == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(ns == 2u) ? 2u : 1u)));
+		// likewise the alpha fields: modes 0-3 are opaque
+		const bool wave_alpha = FIXED_MODE >= 0 ? FIXED_MODE >= 4 : (IMPL == 0 || __builtin_amdgcn_ballot_w64(mode >= 4u) != 0);
 		uint32_t ep[6] = {};
 #pragma unroll
 		for (int e = 0; e < 6; e++) {
@@ -233,7 +235,7 @@ template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
 			x = and_or(0u - p, 0x010101u, x << has_p);
 			x = and_or(x >> c_down, c_keep, x << c_up);		// each byte holds cprec bits: nothing crosses a byte
 			uint32_t a = 0xFF000000u;				// :176-179; modes with alpha have at most two subsets
-			if (e < 4) {
+			if (e < 4 && wave_alpha) {
 				a = ubfe(wa, L.offa[e], ab);
 				a = and_or(p, epb, a << epb);
 				a = ((a << a_up) | (a >> a_down)) << 24;	// bits above the byte fall off the top

@@ -30,3 +30,7 @@ b2[m2, 0] = (b2[m2, 0] & 0xFC) | 0x02
 timeit(b2, "no three-subset modes (0 -> 6, 2 -> 1)")
 b3 = base.copy(); b3[:, 0] = (b3[:, 0] & 0x80) | 0x40      # all mode 6
 timeit(b3, "mode 6 only")
+b4 = base.copy()
+hi_modes = ((b4[:, 0] & 0x0F) == 0) & (b4[:, 0] != 0)      # modes 4-7 -> mode 3
+b4[hi_modes, 0] = (b4[hi_modes, 0] & 0xF0) | 0x08
+timeit(b4, "opaque modes only (4-7 -> 3)")
