@@ -268,22 +268,27 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		default: p = bc6h_mode<13>(b, ep); break;
 		}
 		const bool two = mode < 10u;
+		// a wave of one-subset blocks only (modes 10-13: what encoders emit for smooth HDR content) does not
+		// transform / unquantise the second subset's endpoints (wave-uniform; the random stream never qualifies)
+		const bool wave_two = __builtin_amdgcn_ballot_w64(two) != 0;
 		const uint32_t delta[3] = { p.dr, p.dg, p.db };
 		int32_t q[3][4];
-#pragma unroll
-		for (int c = 0; c < 3; c++) {
-			// :487-518 sign extension and delta transform, :520-533 unquantisation
+		// :487-518 sign extension and delta transform, :520-533 unquantisation
+		auto endpoint = [&](int c, int e) {
 			const int32_t e0 = SIGNED ? sbfe(ep[c][0], 0, p.epb) : (int32_t)ep[c][0];
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				int32_t v = e0;
-				if (e > 0) {
-					const uint32_t t = ubfe((uint32_t)(e0 + sbfe(ep[c][e], 0, delta[c])), 0, p.epb);
-					const uint32_t raw = delta[c] ? t : ep[c][e];
-					v = SIGNED ? sbfe(raw, 0, p.epb) : (int32_t)raw;
-				}
-				q[c][e] = SIGNED ? bc6h_unquantize_signed(v, p.epb) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
+			int32_t v = e0;
+			if (e > 0) {
+				const uint32_t t = ubfe((uint32_t)(e0 + sbfe(ep[c][e], 0, delta[c])), 0, p.epb);
+				const uint32_t raw = delta[c] ? t : ep[c][e];
+				v = SIGNED ? sbfe(raw, 0, p.epb) : (int32_t)raw;
 			}
+			q[c][e] = SIGNED ? bc6h_unquantize_signed(v, p.epb) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
+		};
+#pragma unroll
+		for (int c = 0; c < 3; c++) { endpoint(c, 0); endpoint(c, 1); q[c][2] = 0; q[c][3] = 0; }
+		if (wave_two) {
+#pragma unroll
+			for (int c = 0; c < 3; c++) { endpoint(c, 2); endpoint(c, 3); }
 		}
 		// partition (5 bits at block bit 77), anchor, index stream (:535-564)
 		const uint32_t part = two ? ubfe(blk.z, 13, 5) : 0u;
@@ -304,6 +309,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		LaneRows<uint2, 2, 82> row_b;		// diff g, b
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
+			if (s == 1 && !wave_two) break;
 			uint4 ra; uint2 rb;
 			ra.x = (uint32_t)(q[0][2 * s] * 64 + 32);
 			ra.y = (uint32_t)(q[1][2 * s] * 64 + 32);
