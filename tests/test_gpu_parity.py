@@ -372,6 +372,28 @@ def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), want_l)
 
 
+@pytest.mark.parametrize("name,W,H", [("BC1", 32768, 32768), ("BPTC_FLOAT", 32768, 4096)])
+def test_maximum_size_textures(name, W, H, torch_cuda, oracle):
+    """the largest configurations of BASELINE.json (32768-wide; 4 GiB / 1 GiB of pixels): 64-bit addressing and the
+    block index arithmetic, checked bit-exact at the top, middle and bottom block rows"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    wb, hb = W // 4, H // 4
+    data = np.random.default_rng(5).integers(0, 256, size=wb * hb * fmt.block_bytes, dtype=np.uint8)
+    d = torch.from_numpy(data).cuda()
+    out = torch.empty(W * H * fmt.pixel_bytes, dtype=torch.uint8, device="cuda")
+    binding.decompress_linear_device(fmt, d, W, H, out=out)
+    torch.cuda.synchronize()
+    rows = 4
+    for r0 in (0, hb // 2 - 1, hb - rows):
+        _, want = oracle.linear(fmt, data[r0 * wb * fmt.block_bytes:(r0 + rows) * wb * fmt.block_bytes], W, rows * 4)
+        got = out[r0 * 4 * W * fmt.pixel_bytes:(r0 + rows) * 4 * W * fmt.pixel_bytes].cpu().numpy()
+        assert np.array_equal(got, want), (name, r0)
+    del d, out
+    torch.cuda.empty_cache()
+
+
 def test_empty_inputs(hiplib, torch_cuda):
     """empty textures / zero blocks: the reference's loops simply do not run (texture.c:111-144 -> true, nothing
     written); no launch with an empty grid, no error text"""
