@@ -120,6 +120,10 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 				return hipGetLastError();
 			}
 		}
+		if (EPI == kEpiNone && g.variant == 6) {	// A/B: XCD-contiguous tile order
+			hipLaunchKernelGGL((decode_linear<Dec, kEpiNone, true, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			return hipGetLastError();
+		}
 		if (EPI != kEpiNone || g.variant != 2)	// default: non-temporal row stores (43 vs 51 us on BC1 8192^2)
 			hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 		else
@@ -304,7 +308,7 @@ int current_variant() {
 	if (c.variant < 0) {
 		const char *env = getenv("DETEXHIP_VARIANT");
 		c.variant = env ? atoi(env) : 0;
-		if (c.variant < 0 || c.variant > 5) c.variant = 0;
+		if (c.variant < 0 || c.variant > 6) c.variant = 0;
 	}
 	return c.variant;
 }
@@ -369,7 +373,7 @@ extern "C" int detexhipSetDevice(int device) {
 
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
-extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 5) ? variant : 0; }
+extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 6) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
 
 extern "C" const char *detexhipKernelName(uint32_t texture_format) {

@@ -179,13 +179,17 @@ DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_
 }
 
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
-template <class Dec, int EPI, bool NT>
+template <class Dec, int EPI, bool NT, bool XCD_CHUNKS = false>
 __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
 	prepare_tables<Dec>();
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	// XCD_CHUNKS (A/B, variant 6): workgroups are dealt round-robin to the 8 XCDs, so giving workgroup w the tile
+	// (w % 8) * (grid / 8) + w / 8 makes every XCD (and its L2) own one contiguous eighth of the image instead of
+	// every eighth 4 KiB row segment.  Measured no better than the plain order.
+	const uint32_t tile = XCD_CHUNKS && (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+	const uint32_t i = tile * 256u + threadIdx.x;
 	if constexpr (ROW == 8 && NT) {
 		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
 		const bool live = i < n_blocks;

@@ -112,6 +112,7 @@ DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *
  *      descriptor words; BPTC texel stage selecting subset endpoints with v_bfi chains (no LDS rows)
  *   4  as 0, BPTC block fields extracted from registers instead of an LDS copy of the block
  *   5  BPTC with mode-sorted waves (workgroup counting sort by mode; measured slower, kept for the record)
+ *   6  as 0 with XCD-contiguous tile order (each XCD decodes one contiguous eighth of the image)
  * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);

@@ -268,7 +268,7 @@ def test_blocks_ragged_counts(fmt, torch_cuda, oracle):
         assert np.array_equal(got[:n * 16 * px], want_t.reshape(-1)) and (got[n * 16 * px:] == 0xA5).all(), (fmt.name, n, "tiled")
 
 
-@pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC", 5), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3)])
+@pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC", 5), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3), ("BC1", 6), ("BPTC", 6)])
 def test_alternative_decoder_variants_match(name, variant, torch_cuda, oracle, forced_vectors):
     """the A/B decoder implementations decode identically, forced classes included"""
     from detex_amd import binding
