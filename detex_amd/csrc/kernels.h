@@ -224,6 +224,24 @@ template <int ROW> DH void store_pixel(uint8_t *dst, const uint32_t *row, int x)
 	else { reinterpret_cast<uint32_t *>(dst)[0] = row[2 * x]; reinterpret_cast<uint32_t *>(dst)[1] = row[2 * x + 1]; }
 }
 
+// one texel row of ROW dwords to a destination that is only dword-aligned
+template <int ROW> DH void store_row_dword_aligned(uint8_t *dst, const uint32_t *d) {
+	typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+	typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	typedef v2 v2a __attribute__((aligned(4)));
+	typedef v3 v3a __attribute__((aligned(4)));
+	typedef v4 v4a __attribute__((aligned(4)));
+	if constexpr (ROW == 1) __builtin_nontemporal_store(d[0], reinterpret_cast<uint32_t *>(dst));
+	else if constexpr (ROW == 2) __builtin_nontemporal_store(v2{ d[0], d[1] }, reinterpret_cast<v2a *>(dst));
+	else if constexpr (ROW == 3) __builtin_nontemporal_store(v3{ d[0], d[1], d[2] }, reinterpret_cast<v3a *>(dst));
+	else {
+#pragma unroll
+		for (int k = 0; k < ROW / 4; k++)
+			__builtin_nontemporal_store(v4{ d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }, reinterpret_cast<v4a *>(dst) + k);
+	}
+}
+
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
@@ -236,14 +254,24 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
 	uint32_t by, bx;
 	split_index(i, width_in_blocks, by, bx);
+	// blocks that lie completely inside the image write whole texel rows (vector stores that need only dword
+	// alignment: gfx950 global stores may be unaligned beyond that); only the blocks on the right / bottom edge, or
+	// every block when rows are not even dword-aligned, go pixel by pixel.  BC1 8190x8190: 102 -> 63 us (8192x8192: 43).
+	const bool rows_dword_aligned = ((reinterpret_cast<uintptr_t>(pixels) | pitch) & 3u) == 0;
+	if (rows_dword_aligned && bx * 4u + 4u <= width && by * 4u + 4u <= height) {
+		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 #pragma unroll
-	for (int r = 0; r < 4; r++) {
-		const uint32_t y = by * 4u + r;
-		if (y >= height) continue;
-		uint8_t *dst = pixels + (uint64_t)y * pitch + (uint64_t)bx * (4u * ROW);
+		for (int r = 0; r < 4; r++) store_row_dword_aligned<ROW>(dst + (uint64_t)r * pitch, o + r * ROW);
+	} else {
 #pragma unroll
-		for (int x = 0; x < 4; x++)
-			if (bx * 4u + x < width) store_pixel<ROW>(dst + x * ROW, o + r * ROW, x);
+		for (int r = 0; r < 4; r++) {
+			const uint32_t y = by * 4u + r;
+			if (y >= height) continue;
+			uint8_t *dst = pixels + (uint64_t)y * pitch + (uint64_t)bx * (4u * ROW);
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				if (bx * 4u + x < width) store_pixel<ROW>(dst + x * ROW, o + r * ROW, x);
+		}
 	}
 	raise_status(!ok, status);
 }
