@@ -6,7 +6,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := detex_amd/csrc
 LIB   := detex_amd/lib/libdetexhip.so
-HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
+LIB_AB := detex_amd/lib/libdetexhip_ab.so
+HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/ab/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
 
 all: lib oracle ubench
 lib: $(LIB)
@@ -19,10 +20,17 @@ $(LIB): $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp $(HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
 		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp
 
+# measurement build with the rejected A/B kernels of DESIGN.md section 5 (DETEXHIP_LIB=$(LIB_AB) bench.py --variant N)
+lib-ab: $(LIB_AB)
+$(LIB_AB): $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp $(HDRS)
+	@mkdir -p detex_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DDETEXHIP_AB_VARIANTS \
+		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(LIB) tools/ubench/valu_rates
+	rm -f $(LIB) $(LIB_AB) tools/ubench/valu_rates
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle ubench clean
+.PHONY: all lib lib-ab oracle ubench clean

@@ -5,16 +5,19 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1 via tor
 prints ONE JSON line on rank 0.
 
   step      one pass of the hot path over one batch: one detexhipDecompressTextureLinearDevice
-            call (= one kernel launch) decoding a whole width x height block stream that is
-            already resident in HBM into a device-resident linear image.
-  workload  BASELINE.json configs[1]: BC1 -> RGBA8, 8192 x 8192, synthetic stream U
-            (splitmix64, tests/oracle_lib.py).  Other formats: --format NAME (parity-test
-            configs, reported to stderr / --formats-json, not the headline line).
-  N > 1     the path shards by block rows with no data-path collective: every
-            rank decodes its own 8192-row band of a 8192 x (8192*N) image -> "scaling": "weak".
-            RCCL is used only for the timing barrier / max-reduction (and the optional gather,
-            --gather, which is reported separately and is not part of `value`).
-  value     Gpixel/s = N * width * height * K / max-over-ranks(wall time of K steps)
+            call (= one kernel launch) decoding a whole block stream that is already resident in
+            HBM into a device-resident linear image.
+  N == 1    workload = BASELINE.json configs[1]: BC1 -> RGBA8, 8192 x 8192, synthetic stream U
+            (splitmix64, tests/oracle_lib.py).  Extra keys: `per_format` (the six headline formats
+            of configs[1..4] at 8192^2, streams U/M/C, each timed at steady state),
+            `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`, `cpu_baseline`.
+  N > 1     BASELINE north_star: ONE 32768 x 32768 BC1 image sharded by block rows over the ranks
+            (contiguous input and output ranges per rank, NO data-path collective)
+            -> "scaling": "strong", value = 32768^2 * K / max-over-ranks(wall time of K steps).
+            RCCL is used for the timing barrier / max-reduction only.  Extra keys: `weak` (one
+            8192^2 image per rank), `gather` (the optional whole-image all-gather over xGMI through
+            detex_amd.sharding.gather_image, timed separately, never part of `value`),
+            `rccl_ranks` (ranks that answered an all_reduce).  --weak restores the round-1 line.
   roofline  algorithmic bytes per launch (blocks * (block_bytes + 16*pixel_bytes)) / average
             launch duration from HIP events recorded on the launch stream around the timed
             region; peak = 8 TB/s (MI355X_MICROARCH.md).
@@ -26,7 +29,6 @@ import ctypes
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -36,6 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0
+HEADLINE_FORMATS = ["BC1", "BC3", "BPTC", "ETC2", "ETC2_EAC", "BPTC_FLOAT"]
 
 
 def log(*a):
@@ -100,22 +103,24 @@ def main():
     ap.add_argument("--format", default="BC1")
     ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
     ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
-    ap.add_argument("--strong-image", type=int, default=0,
-                    help="strong scaling: ONE S x S image sharded by block rows over the ranks (BASELINE north_star: 32768); "
-                         "each rank decodes its S x S/N band, value = S*S*steps/time, \"scaling\": \"strong\"")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (include/detexhip.h)")
-    ap.add_argument("--stream", default="U", choices=["U", "M"])
+    ap.add_argument("--strong-image", type=int, default=None,
+                    help="strong scaling: ONE S x S image sharded by block rows over the ranks; default 32768 (BASELINE "
+                         "north_star) when N > 1, off when N == 1")
+    ap.add_argument("--weak", action="store_true", help="N > 1: one --size^2 image per rank as the headline (round-1 behaviour)")
+    ap.add_argument("--variant", type=int, default=0, help="A/B kernel variant (needs DETEXHIP_LIB=<make lib-ab build>)")
+    ap.add_argument("--stream", default="U", choices=["U", "M", "C"])
     ap.add_argument("--layout", default="linear", choices=["linear", "tiled"],
                     help="linear = detexDecompressTextureLinear (headline); tiled = detexDecompressTextureTiled (block-major output)")
     ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--gather", action="store_true", help="also time the optional whole-image all-gather (N>1)")
-    ap.add_argument("--formats-json", default=None, help="also bench every format, write a table to this path")
+    ap.add_argument("--no-extras", action="store_true", help="skip per_format / strong_image_32768 / weak / gather extras")
+    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is timed by default when N > 1)")
+    ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from detex_amd import binding, formats as F
+    from detex_amd import binding, formats as F, sharding
     import oracle_lib as ol
     import streams
 
@@ -133,14 +138,19 @@ def main():
     backend = os.environ.get("DETEX_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())          # ranks the collective library actually reached
     binding.load()
     binding.set_kernel_variant(args.variant)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,144 +158,281 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_input(fmt, W, H, seed_shift):
-        data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=ol.STREAM_SEED_BASE + ol.STREAM_SEED_K.get(fmt.name, 16 + fmt.index) + (seed_shift << 8))
-        if args.stream == "M":
-            data = streams.stream_m(fmt, data)
-        return data
-
     TARGETS = {"BGRA8": F.PIXEL_FORMAT_BGRA8, "BGRX8": F.PIXEL_FORMAT_BGRX8, "RGB8": F.PIXEL_FORMAT_RGB8,
                "FLOAT_BGRX16": F.PIXEL_FORMAT_FLOAT_BGRX16, "RGBA8": F.PIXEL_FORMAT_RGBA8}
 
-    def target_of(fmt):
-        pf = TARGETS[args.target] if args.target else F.native_pixel_format(fmt)
+    def target_of(fmt, target=None):
+        pf = TARGETS[target] if target else F.native_pixel_format(fmt)
         return pf, 1 + ((pf & 0xF00) >> 8)
 
-    def run_format(fmt, W, H, steps, warmup):
-        data = make_input(fmt, W, H, rank)
-        d_blocks = torch.from_numpy(np.ascontiguousarray(data)).cuda()
-        pf, tpx = target_of(fmt)
-        d_out = torch.empty(W * H * tpx, dtype=torch.uint8, device="cuda")
-        status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        if args.layout == "tiled":
-            step = lambda: binding.decompress_tiled_device(fmt, d_blocks, W // 4, H // 4, out=d_out, status=status, pixel_format=pf)
-        else:
-            step = lambda: binding.decompress_linear_device(fmt, d_blocks, W, H, out=d_out, status=status, pixel_format=pf)
+    def stream_seed(fmt, shift):
+        return ol.STREAM_SEED_BASE + ol.STREAM_SEED_K.get(fmt.name, 16 + fmt.index) + (shift << 8)
+
+    def make_input(fmt, wb, hb, kind, seed_shift=0):
+        return streams.make_stream(kind, fmt, wb, hb, seed=stream_seed(fmt, seed_shift))
+
+    class Job:
+        """device-resident input/output of one decode call"""
+        def __init__(self, fmt, W, H, data, layout="linear", target=None):
+            self.fmt, self.W, self.H, self.data, self.layout = fmt, W, H, data, layout
+            self.pf, self.tpx = target_of(fmt, target)
+            self.d_blocks = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+            self.d_out = torch.empty(W * H * self.tpx, dtype=torch.uint8, device="cuda")
+            self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
+            self.blocks = (W // 4) * (H // 4)
+            self.alg_bytes = self.blocks * (fmt.block_bytes + 16 * self.tpx)
+
+        def step(self):
+            if self.layout == "tiled":
+                binding.decompress_tiled_device(self.fmt, self.d_blocks, self.W // 4, self.H // 4, out=self.d_out, status=self.status, pixel_format=self.pf)
+            else:
+                binding.decompress_linear_device(self.fmt, self.d_blocks, self.W, self.H, out=self.d_out, status=self.status, pixel_format=self.pf)
+
+        def verify(self, rows=64):
+            """bit-exactness of what was just timed against the CPU checker on a bounded sample (first `rows` block rows)"""
+            rows = min(rows, self.H // 4)
+            orc = ol.Oracle()
+            sub = self.data[:rows * (self.W // 4) * self.fmt.block_bytes]
+            if self.layout == "tiled":
+                _, want = orc.tiled_to(self.fmt, sub, self.W // 4, rows, self.pf)
+            else:
+                _, want = orc.linear_to(self.fmt, sub, self.W, rows * 4, self.pf)
+            got = self.d_out[:want.size].cpu().numpy()
+            return rows * 4 if np.array_equal(got, want) else 0
+
+    def timed(job, steps, warmup):
+        """the contract's timed region: W warm-up launches, then exactly K launches between barriers; wall = max over ranks"""
         for _ in range(warmup):
-            step()
+            job.step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
-            step()
+            job.step()
         e1.record()
         barrier()
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
         if world > 1:
-            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, ev_ms = t.tolist()
-        return data, d_blocks, d_out, wall, ev_ms / steps
+        return wall, ev_ms / steps
+
+    def steady_state_us(job, window=100, max_windows=10, tol=0.03):
+        """launch time once the power-management transient of VALU-heavy kernels has passed (DESIGN.md section 6:
+        20-40 % slower for launches ~25-300): windows of `window` launches until two consecutive ones agree within
+        `tol` and at least 400 launches have run; independent of the driver's --steps / --warmup"""
+        prev, done, us = None, 0, None
+        for _ in range(max_windows):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(window):
+                job.step()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / window * 1e3
+            done += window
+            if prev is not None and done >= 400 and abs(us - prev) <= tol * prev:
+                break
+            prev = us
+        return us, done
+
+    def roofline_of(job, launch_us):
+        ach = job.alg_bytes / (launch_us * 1e-6) / 1e9
+        return {"launch_us": round(launch_us, 2), "gpixel_s": round(job.W * job.H / (launch_us * 1e-6) / 1e9, 1),
+                "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)}
+
+    def pmc_traffic(key):
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            return json.load(open(pmc)).get(key)
+        except Exception:  # noqa
+            return None
 
     fmt = F.BY_NAME[args.format]
+    strong = args.strong_image if args.strong_image is not None else (0 if (world == 1 or args.weak) else 32768)
     W = H = args.size
     if args.band_height:
         H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
-    if args.strong_image:
-        from detex_amd import sharding
-        shard = sharding.shard_of(rank, world, fmt, args.strong_image, args.strong_image)
-        W, H = args.strong_image, (shard.row1 - shard.row0) * 4
-    data, d_blocks, d_out, wall, launch_ms = run_format(fmt, W, H, args.steps, args.warmup)
-    blocks = (W // 4) * (H // 4)
-    pf, tpx = target_of(fmt)
-    alg_bytes = blocks * (fmt.block_bytes + 16 * tpx)
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    gpix = world * W * H * args.steps / wall / 1e9
+    if strong:
+        shard = sharding.shard_of(rank, world, fmt, strong, strong)
+        W, H = strong, (shard.row1 - shard.row0) * 4
+    if strong and args.stream != "C":
+        # the image's stream is defined over the whole image; a rank materialises only its band of it
+        wb = W // 4
+        words_per_row = wb * fmt.block_bytes // 8
+        seed = stream_seed(fmt, 0)
+        # splitmix64 is counter-based: word k depends on k only, so the band is the slice [row0*wpr, row1*wpr)
+        with np.errstate(over="ignore"):
+            k = np.arange(shard.row0 * words_per_row + 1, shard.row1 * words_per_row + 1, dtype=np.uint64)
+            z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * k
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        data = z.view(np.uint8)
+        if args.stream == "M":
+            data = streams.stream_m(fmt, data)
+    else:
+        data = make_input(fmt, W // 4, H // 4, args.stream, 0 if strong else rank)
+        if data is None:
+            log("bench.py: stream C needs a bundled fixture of", fmt.name)
+            sys.exit(4)
+    job = Job(fmt, W, H, data, args.layout, args.target)
+    wall, launch_ms = timed(job, args.steps, args.warmup)
+    image_pixels = strong * strong if strong else world * W * H
+    gpix = image_pixels * args.steps / wall / 1e9
+    achieved = job.alg_bytes / (launch_ms * 1e-3) / 1e9
 
-    gather = None
-    if args.gather and world > 1:
-        full = torch.empty(world * d_out.numel(), dtype=torch.uint8, device="cuda")
-        dist.all_gather_into_tensor(full, d_out)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            dist.all_gather_into_tensor(full, d_out)
-        barrier()
-        gather = {"op": "all_gather_into_tensor", "ms": (time.perf_counter() - t0) / 5 * 1e3, "bytes_per_rank": d_out.numel()}
+    # what every rank just wrote, checked against the CPU oracle on a bounded sample; AND over ranks
+    verified_rows = job.verify(64 if world == 1 else 16)
+    if world > 1:
+        v = torch.tensor([verified_rows], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified_rows = int(v.item())
+
+    extras = {}
+    if world > 1 and not args.no_extras:
+        # (a) the optional whole-image gather, through the library function (one all_gather_into_tensor straight into the image)
+        if strong:
+            try:
+                ok, image = sharding.gather_image(dist, torch, fmt, strong, strong, shard, job.d_out, True)
+                barrier()
+                t0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    ok, image = sharding.gather_image(dist, torch, fmt, strong, strong, shard, job.d_out, True, image=image)
+                barrier()
+                g_ms = (time.perf_counter() - t0) / reps * 1e3
+                mine = image[shard.out_offset:shard.out_offset + shard.out_bytes]
+                same = bool(torch.equal(mine, job.d_out[:shard.out_bytes]))
+                other = sharding.shard_of((rank + 1) % world, world, fmt, strong, strong)
+                probe = image[other.out_offset:other.out_offset + 4096].cpu().numpy()
+                extras["gather"] = {"op": "sharding.gather_image (all_gather_into_tensor into the final image)", "ms": round(g_ms, 3),
+                                    "bytes_per_rank": int(shard.out_bytes), "image_bytes": int(image.numel()),
+                                    "GBps_received_per_rank": round((image.numel() - shard.out_bytes) / (g_ms * 1e-3) / 1e9, 1),
+                                    "own_band_intact": same, "peer_band_nonzero": bool(probe.any()),
+                                    "decode_plus_gather_ms": round(wall / args.steps * 1e3 + g_ms, 3)}
+                del image
+            except Exception as e:  # noqa
+                extras["gather"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        # (b) weak scaling: one 8192^2 image per rank
+        if strong:
+            wjob = Job(fmt, args.size, args.size, make_input(fmt, args.size // 4, args.size // 4, args.stream if args.stream != "C" else "U", rank), args.layout, args.target)
+            w_wall, w_ms = timed(wjob, args.steps, args.warmup)
+            extras["weak"] = {"workload": "%s %dx%d per GPU" % (fmt.name, args.size, args.size), "value_gpixel_s": round(world * args.size * args.size * args.steps / w_wall / 1e9, 3),
+                              "ms_per_step": round(w_wall / args.steps * 1e3, 5), "launch_us": round(w_ms * 1e3, 3)}
+            del wjob
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    tname = F.PIXEL_FORMAT_NAMES.get(job.pf, "0x%04X" % job.pf)
+    if strong:
+        workload = ("%s->%s, ONE %dx%d image (stream %s, splitmix64 seed 0xD37E5000+k) sharded by block rows over %d GPU(s): "
+                    "one %d-row band per GPU, one launch per step, no data-path collective" % (fmt.name, tname, strong, strong, args.stream, world, H))
+    else:
+        workload = ("%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, one image per GPU"
+                    % (fmt.name, tname, W, H, args.stream))
     result = {
-        "metric": "Gpixel/s decoded (%s -> %s, %dx%d per GPU, device-resident)" % (fmt.name, F.target_name(fmt), W, H),
+        "metric": "Gpixel/s decoded (%s -> %s, %s, device-resident)" % (fmt.name, tname, ("%dx%d image over %d GPU(s)" % (strong, strong, world)) if strong else "%dx%d per GPU" % (W, H)),
         "value": round(gpix, 3), "unit": "Gpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong" if args.strong_image else "weak",
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, "
-                               "sharded by block rows: one %d-row band per GPU" % (fmt.name, F.target_name(fmt), W, H, args.stream, H),
-                   "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": blocks,
-                   "kernel": binding.kernel_name(fmt) if args.layout == "linear" else "decode_blocks", "layout": args.layout, "variant": args.variant, "target_pixel_format": "0x%04X" % pf},
+        "config": {"workload": workload, "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": job.blocks, "stream": args.stream,
+                   "kernel": binding.kernel_name(fmt) if args.layout == "linear" else "decode_blocks", "layout": args.layout, "variant": args.variant,
+                   "target_pixel_format": "0x%04X" % job.pf},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
-                     "write_frac": round(blocks * 16 * tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "algorithmic_bytes_per_launch": job.alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
+                     "write_frac": round(job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "verified_bit_exact_rows": verified_rows,
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            key = "%s/%d/v%d" % (fmt.name, W, args.variant) + ("/%s" % args.target if args.target else "")
-            t = json.load(open(pmc)).get(key)
-            if t:
-                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = t.get("source")
-        except Exception as e:  # noqa
-            log("pmc_traffic.json unreadable:", e)
-    if gather:
-        result["gather"] = gather
+    if verified_rows == 0:
+        log("bench.py: OUTPUT MISMATCH against the oracle")
+        result["value"] = 0.0
+    t = pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
+    if t:
+        result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        result["roofline"]["traffic_source"] = t.get("source")
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks
+        result["collective_backend"] = backend
+    result.update(extras)
 
     if world == 1:
-        # bit-exactness of what was just timed, against the CPU checker on a bounded sample (first 64 block rows)
-        rows = 64
-        orc = ol.Oracle()
-        if args.layout == "tiled":
-            ok_o, want = orc.tiled_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W // 4, rows, pf)
-        else:
-            ok_o, want = orc.linear_to(fmt, data[:rows * (W // 4) * fmt.block_bytes], W, rows * 4, pf)
-        got = d_out[:want.size].cpu().numpy()
-        result["verified_bit_exact_rows"] = rows * 4 if np.array_equal(got, want) else 0
-        if not np.array_equal(got, want):
-            log("bench.py: OUTPUT MISMATCH against the oracle")
-            result["value"] = 0.0
         # host-pointer drop-in tier (PCIe-inclusive; never `value`)
         try:
             if args.layout != "linear":
                 raise RuntimeError("host tier is timed for the linear layout only")
             api = ol.DetexAPI(binding.LIB_PATH)
-            host_out = np.empty(W * H * tpx, np.uint8)
-            api.linear(fmt, data, W, H, out=host_out, pixel_format=pf)
-            t0 = time.perf_counter(); api.linear(fmt, data, W, H, out=host_out, pixel_format=pf); th = time.perf_counter() - t0
-            result["host_tier"] = {"gpixel_s_pcie_inclusive": round(W * H / th / 1e9, 3), "ms": round(th * 1e3, 2)}
+            host_out = np.empty(W * H * job.tpx, np.uint8)
+            api.linear(fmt, data, W, H, out=host_out, pixel_format=job.pf)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter(); api.linear(fmt, data, W, H, out=host_out, pixel_format=job.pf); th = time.perf_counter() - t0
+                best = th if best is None or th < best else best
+            result["host_tier"] = {"gpixel_s_pcie_inclusive": round(W * H / best / 1e9, 3), "ms": round(best * 1e3, 2)}
         except Exception as e:  # noqa
             log("host tier timing failed:", e)
-        if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(fmt, data, W, H)
+
+    if world == 1 and not args.no_extras and not args.formats_json:
+        # per-format table of the headline formats (BASELINE configs[1..4]) at 8192^2, steady state, streams U / M / C
+        table = {}
+        t_start = time.perf_counter()
+        for name in HEADLINE_FORMATS:
+            f = F.BY_NAME[name]
+            for kind in (["U", "M", "C"] if name in ("BPTC", "BPTC_FLOAT") else ["U", "C"]):
+                d = make_input(f, 2048, 2048, kind)
+                if d is None:
+                    continue
+                j = Job(f, 8192, 8192, d)
+                us, launches = steady_state_us(j)
+                row = roofline_of(j, us)
+                row["launches_before_reading"] = launches
+                tr = pmc_traffic("%s/8192/linear" % name)
+                if tr and kind == "U":
+                    row["traffic"] = tr["hbm_bytes_per_launch"]
+                table["%s/%s" % (name, kind)] = row
+                del j
+        torch.cuda.empty_cache()
+        result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 3 % and >= 400 launches ran)",
+                                "seconds": round(time.perf_counter() - t_start, 2), "formats": table}
+        # this GPU alone on the N > 1 workload (so the driver's scaling curve has a like-for-like N = 1 point)
+        try:
+            f = F.BY_NAME["BC1"]
+            d = ol.stream_u(f, 8192 * 2048, seed=stream_seed(f, 0))          # the first quarter of the image's stream, decoded as four bands' worth
+            j = Job(f, 32768, 8192, d)
+            us, _ = steady_state_us(j, window=20, max_windows=4)
+            result["strong_image_32768"] = {"note": "one GPU decoding a 32768x8192 band (a quarter of the 32768^2 BC1 image; the whole image is 4 launches of this size)",
+                                            "band_launch_us": round(us, 2), "gpixel_s": round(32768 * 8192 / (us * 1e-6) / 1e9, 1),
+                                            "frac": round(j.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+            del j
+        except Exception as e:  # noqa
+            log("strong_image_32768 failed:", e)
+        torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(fmt, data, W, H)
 
     if args.formats_json and world == 1:
         table = {}
         for f in F.FORMATS:
-            for kind in (["U", "M"] if f.name in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT") else ["U"]):
-                args.stream = kind
-                args.target = None
-                _, _, _, w_, ms_ = run_format(f, W, H, max(200, args.steps), 400)    # steady state: the first ~300 launches of a VALU-heavy kernel ride a power-management transient
-                ab = blocks * (f.block_bytes + 16 * f.pixel_bytes)
-                table["%s/%s" % (f.name, kind)] = {"launch_us": round(ms_ * 1e3, 2), "gpixel_s": round(W * H / (ms_ * 1e-3) / 1e9, 1),
-                                                    "achieved_GBps": round(ab / (ms_ * 1e-3) / 1e9, 1),
-                                                    "frac_of_8TBps": round(ab / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            for kind in ["U", "M", "C"]:
+                if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT"):
+                    continue
+                d = make_input(f, W // 4, H // 4, kind)
+                if d is None:
+                    continue
+                j = Job(f, W, H, d, args.layout)
+                us, launches = steady_state_us(j)
+                table["%s/%s" % (f.name, kind)] = roofline_of(j, us)
                 log(f.name, kind, table["%s/%s" % (f.name, kind)])
+                del j
                 torch.cuda.empty_cache()
         os.makedirs(os.path.dirname(os.path.abspath(args.formats_json)), exist_ok=True)
         json.dump(table, open(args.formats_json, "w"), indent=1, sort_keys=True)

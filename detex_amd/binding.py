@@ -10,7 +10,8 @@ import os
 from . import formats as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdetexhip.so")
+# DETEXHIP_LIB selects another build of the same ABI (the A/B measurement build, `make lib-ab`)
+LIB_PATH = os.environ.get("DETEXHIP_LIB") or os.path.join(_HERE, "lib", "libdetexhip.so")
 _lib = None
 
 _vp = ctypes.c_void_p

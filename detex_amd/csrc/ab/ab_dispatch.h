@@ -1,0 +1,56 @@
+// ab/ab_dispatch.h -- launch-side selection of the rejected A/B kernels.
+// Only compiled with -DDETEXHIP_AB_VARIANTS (make lib-ab); the product library contains none of this.
+//   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)           [BC1 only]
+//   2  default mapping with ordinary (cached) row stores
+//   3  BPTC_FLOAT field scatter as a per-mode switch; BPTC round-1 decoder with register-select texel stage
+//   4  BPTC round-1 default decoder (LDS block fields, per-texel index widths) -- the baseline decode_bptc.h replaced
+//   5  BPTC with mode-sorted waves (workgroup counting sort by mode)
+// Included by detexhip.hip inside its anonymous namespace, after Geometry / PlainDecoder (the kernel headers
+// variant_tile4x4.h, decode_bptc_r01.h and kernels_sorted.h are included at file scope before it).
+#pragma once
+
+template <class Dec> struct AltDecoder { using type = Dec; };
+template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };
+template <> struct AltDecoder<DecBPTC> { using type = r01::DecBPTCRegisterSelect; };
+template <class Dec> struct AltDecoder2 { using type = Dec; };
+template <> struct AltDecoder2<DecBPTC> { using type = r01::DecBPTCLdsFields; };
+
+// returns true if variant g.variant exists for <Dec, EPI> and was launched (*result = launch status)
+template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_t *result) {
+	const uint32_t n = g.wb * g.hb;
+	const dim3 grid((n + 255u) / 256u), block(256);
+	uint8_t *px = static_cast<uint8_t *>(g.pixels);
+	if (EPI == kEpiNone && g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0) {
+		*result = Tile4x4<Dec>::launch(g.blocks, px, g.wb, g.hb, g.pitch, g.status, g.stream);
+		return true;
+	}
+	if constexpr (EPI == kEpiNone) {
+		if (g.variant == 2) {
+			hipLaunchKernelGGL((decode_linear<typename PlainDecoder<Dec>::type, kEpiNone, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
+	if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder<Dec>::type, Dec>) {
+		if (g.variant == 3) {
+			hipLaunchKernelGGL((decode_linear<typename AltDecoder<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
+	if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder2<Dec>::type, Dec>) {
+		if (g.variant == 4) {
+			hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
+	if constexpr (ClassSorted<Dec>::kAvailable && Epilogue<EPI, Dec::kPixelBytes>::kRowDwords == 4) {
+		if (g.variant == 5) {
+			hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
+	return false;
+}

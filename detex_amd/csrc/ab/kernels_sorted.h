@@ -18,8 +18,9 @@
 // extra workgroup barriers and 32 KiB of LDS per workgroup (5 workgroups per CU) leave the SIMDs with too
 // few issuing waves.  A larger sort domain (1024 blocks) was costed at < 10 % fewer instructions.
 #pragma once
-#include "kernels.h"
-#include "decode_bptc.h"
+#include "../kernels.h"
+#include "../decode_bptc.h"
+#include "decode_bptc_r01.h"
 
 namespace detexhip {
 
@@ -36,18 +37,18 @@ template <> struct ClassSorted<DecBPTC> {
 	// all lanes of the calling wave hold class c (wave-uniform)
 	static DH bool decode_uniform(uint32_t c, const uint4 &blk, uint32_t (&d)[16]) {
 		switch (c) {
-		case 0: return DecBPTCMode<0, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 1: return DecBPTCMode<1, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 2: return DecBPTCMode<2, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 3: return DecBPTCMode<3, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 4: return DecBPTCMode<4, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 5: return DecBPTCMode<5, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 6: return DecBPTCMode<6, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
-		case 7: return DecBPTCMode<7, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 0: return r01::DecBPTCMode<0, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 1: return r01::DecBPTCMode<1, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 2: return r01::DecBPTCMode<2, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 3: return r01::DecBPTCMode<3, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 4: return r01::DecBPTCMode<4, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 5: return r01::DecBPTCMode<5, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 6: return r01::DecBPTCMode<6, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
+		case 7: return r01::DecBPTCMode<7, 1>::template decode<false>(blk, 0xFFFFFFFFu, 0u, d);
 		default: return false;				// reserved: zero-filled, raises the status word
 		}
 	}
-	typedef DecBPTCRegisterFields Generic;			// straddling waves: all-modes decoder
+	typedef r01::DecBPTCRegisterFields Generic;			// straddling waves: all-modes decoder
 };
 
 template <class Dec, int EPI, bool NT>
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void decode_linear_sorted(const void *__restri
 
 	const uint32_t tid = threadIdx.x;
 	if (tid < 16u) count[tid] = 0u;
-	prepare_tables<Dec>();
+	prepare_tables<typename S::Generic>();
 	__syncthreads();
 
 	// 1. classify

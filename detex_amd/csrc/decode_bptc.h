@@ -1,359 +1,426 @@
 // decode_bptc.h -- BPTC (BC7), all eight modes, one lane per block, gfx950.
 //
-// The reference decodes with an 8-way mode switch, a bit-at-a-time 128-bit reader and per-texel
-// table lookups (decompress-bptc.c:354-512).  A wavefront of 64 independent blocks would execute
-// every taken mode path serially, so this decoder is a single DIVERGENCE-FREE data-driven path:
-//   * everything about a mode that does not depend on the block (field positions and widths, expansion
-//     shifts, index widths, weight constants) is a Bc7Layout record derived at compile time from the
-//     eight mode descriptors and fetched per lane from a workgroup LDS copy;
-//   * the block's bits and the (up to three) subsets' blend operands live in per-lane LDS rows
-//     (dev_common.h: LaneRows), so a field is two dwords + v_alignbit_b32 and a texel's subset is one
-//     ds_read_b128 instead of register-select chains;
-//   * endpoints are expanded to 8 bits with SWAR byte math, the two index streams are read through two
-//     32-bit windows each (one shift per texel), a weight is one v_mad_u32_u24, and a texel is blended two
-//     channels per v_pk_mad_u16.
-// Partition / anchor tables are the bit-packed words of bptc_tables.inc (__constant__, LDS copy per workgroup).
+// The reference decodes with an 8-way mode switch, a bit-at-a-time 128-bit reader and per-texel table lookups
+// (decompress-bptc.c:354-512).  A wavefront of 64 independent blocks would execute every taken mode path
+// serially, so this decoder is ONE divergence-free data-driven path whose VALU work is kept as small as the
+// format allows (the kernel is VALU-issue-bound, not HBM-bound: DESIGN.md section 4):
+//   * everything about a mode that does not depend on the block -- field positions as (LDS row, shift) pairs,
+//     widths, packed per-lane shift amounts of the 8-bit expansion, P-bit routing, index widths, masks and
+//     weight constants of the colour and alpha index streams -- is a Bc7Rec derived AT COMPILE TIME from the
+//     eight mode descriptors and fetched per lane from a workgroup LDS copy (record 8 = mode 4 with the index
+//     selection bit set, so stream swapping costs nothing);
+//   * the block's bits live in per-lane LDS rows: a field is one address add, one ds_read2st64_b32 and one
+//     v_alignbit_b32;
+//   * endpoints are gathered straight into the 16-bit lanes the blend needs, (R,G) and (B,A), and expanded to
+//     8 bits there with per-lane packed shifts (v_pk_lshlrev_b16 / v_pk_lshrrev_b16) and v_bitop3_b32;
+//   * the anchor texels' missing index bits are INSERTED (w += w & himask: two full-rate ops per anchor, masks
+//     from a compile-time-derived table indexed by partition) so every texel reads its index at a regular
+//     position: `and` + `shift`, both full-rate, instead of per-texel widths;
+//   * a weight is one v_mad_u32_u24 whose high half feeds both lanes of v_pk_mad_u16 through op_sel (no
+//     broadcast instruction); the (up to three) subsets' blend operands sit in per-lane LDS rows at a 16 KiB
+//     aligned base, so a texel's subset row address is one v_bitop3_b32 of the pre-shifted partition word.
+// Partition / anchor constants are the bit-packed words of bptc_tables.inc.
+//
+// Waves whose 64 blocks share one record (encoder output is mode-coherent; the uniform-random stream never
+// is) branch to a copy of the same code with the record as a compile-time constant (DecBPTC; kUniform).
 //
 // Reference quirk reproduced: in mode 6 the second P-bit (block bit 64) reads 0.
 #pragma once
-#include "dev_common.h"
+#include "bptc_common.h"
 #include "decode_s3tc_rgtc.h"
-#include "bptc_tables.inc"
 
 namespace detexhip {
 
-// [0..63] two-subset partitions, [64..127] three-subset partitions; 2-bit subset field per texel
-__constant__ uint32_t kPartition2Bit[128] = { DETEXHIP_P2X_WORDS, DETEXHIP_P3_WORDS };
-// anchor2 | anchor3_second << 4 | anchor3_third << 8
-__constant__ uint16_t kAnchorWords[64] = { DETEXHIP_ANCHOR_WORDS };
-// one-bit-per-texel form of the two-subset partitions (BC6H)
-__constant__ uint16_t kPartition1Bit[64] = { DETEXHIP_P2_WORDS };
-
 // per-mode layout (decompress-bptc.c:24-43 comment table, :45-71, :134, :195-225, :265-267)
-constexpr uint32_t bc7_desc(uint32_t ns, uint32_t pb, uint32_t rb, uint32_t isb, uint32_t cb, uint32_t ab, uint32_t epb,
-		uint32_t spb, uint32_t ib, uint32_t ib2) {
-	return ns | (pb << 2) | (rb << 5) | (isb << 7) | (cb << 8) | (ab << 11) | (epb << 15) | (spb << 16) | (ib << 17) | (ib2 << 20);
-}
+struct Bc7ModeDesc { uint32_t ns, pb, rb, isb, cb, ab, epb, spb, ib, ib2; };
+constexpr Bc7ModeDesc kBc7Modes[8] = {
+	//subsets part rot isel colour alpha endpoint-P shared-P index index2
+	{ 3, 4, 0, 0, 4, 0, 1, 0, 3, 0 }, { 2, 6, 0, 0, 6, 0, 0, 1, 3, 0 }, { 3, 6, 0, 0, 5, 0, 0, 0, 2, 0 }, { 2, 6, 0, 0, 7, 0, 1, 0, 2, 0 },
+	{ 1, 0, 2, 1, 5, 6, 0, 0, 2, 3 }, { 1, 0, 2, 0, 7, 8, 0, 0, 2, 2 }, { 1, 0, 0, 0, 7, 7, 1, 0, 4, 0 }, { 2, 6, 0, 0, 5, 5, 1, 0, 2, 0 } };
 
-// Everything about a mode that does not depend on the block's contents, precomputed (decompress-bptc.c:24-43,
-// :45-71, :134-180): bit positions of the fields, their widths, the shift amounts of the 8-bit expansion, the
-// index widths and their weight constants.  For a per-lane mode the decoder fetches this record from LDS with a
-// few ds_read_b128 instead of deriving it from the descriptor word with ~50 VALU instructions per block.
-struct alignas(16) Bc7Layout {
-	uint32_t pos_part, pb, pos_rot, rb, pos_isel, isb;		// header fields
-	uint32_t pos_r, pos_g, pos_b, pos_a, pos_p, pos_idx, pos_idx2;	// channel words, P-bits, index streams
-	uint32_t cb, ab, off[6], offa[4];				// field widths, e*cb, e*ab
-	uint32_t has_p, epb, p_word_mask, p_double;			// p_word_mask: quirk A-2 (mode 6 keeps one P-bit); p_double: shared P-bit
-	uint32_t c_up, c_down, c_keep, a_up, a_down;
-	uint32_t alpha_keep, alpha_set;					// modes 0-3: alpha = 255
-	uint32_t ns, part_base, ib, ib2;				// part_base: +64 selects the three-subset table
-	uint32_t w_mul, w_add, w2_mul, w2_add;				// weight = byte 2 of index * mul + add, for ib and ib2
+// ---- partition / anchor table -------------------------------------------------------------------------
+// One entry per (partition table, index width) pair a block can name, 6 dwords:
+//   m_lo1, m_lo2   high masks of the zero bits to insert into the first index window (texels 0-7) for the
+//                  anchors of subsets 1 and 2 that lie there, ascending; 0 = none (texel 0's is in the record)
+//   m_hi1, m_hi2   the same for the second window (texels 8-15)
+//   half           bits the first window consumes from the stream = 8*ib - (anchors among texels 0-7)
+//   pword          2-bit subset number per texel
+// Sections: [0,64) two subsets ib 2 (modes 3, 7) . [64,128) two subsets ib 3 (mode 1) . [128,192) three
+// subsets ib 2 (mode 2) . [192,208) three subsets ib 3 (mode 0, 4-bit partition number) . 208/209/210 one
+// subset with ib 2/3/4 (modes 4, 5, 6: only `half` matters).
+constexpr int kBc7PartEntries = 211;
+struct Bc7PartEntry { uint32_t m_lo1, m_lo2, m_hi1, m_hi2, half, pword; };
+struct Bc7PartTable { Bc7PartEntry e[kBc7PartEntries]; };
+constexpr Bc7PartEntry bc7_part_entry(int subsets, uint32_t ib, uint32_t part) {
+	Bc7PartEntry r = {};
+	uint32_t a[2] = { 99u, 99u };
+	if (subsets == 2) { a[0] = kAnchorWordsCx[part] & 15u; r.pword = kPartition2BitCx[part]; }
+	if (subsets == 3) {
+		a[0] = (kAnchorWordsCx[part] >> 4) & 15u; a[1] = (kAnchorWordsCx[part] >> 8) & 15u;
+		r.pword = kPartition2BitCx[64u + part];
+		if (a[0] > a[1]) { const uint32_t t = a[0]; a[0] = a[1]; a[1] = t; }
+	}
+	uint32_t nlo = 1u, lo[2] = { 0u, 0u }, hi[2] = { 0u, 0u }, klo = 0u, khi = 0u;
+	for (int k = 0; k < 2; k++) {
+		if (a[k] > 15u) continue;
+		const uint32_t pos = (a[k] & 7u) * ib + ib - 1u;	// where the anchor's absent MSB belongs in its window
+		const uint32_t himask = 0xFFFFFFFFu << pos;
+		if (a[k] < 8u) { lo[klo++] = himask; nlo++; } else hi[khi++] = himask;
+	}
+	r.m_lo1 = lo[0]; r.m_lo2 = lo[1]; r.m_hi1 = hi[0]; r.m_hi2 = hi[1];
+	r.half = 8u * ib - nlo;
+	return r;
+}
+constexpr Bc7PartTable bc7_part_table() {
+	Bc7PartTable t = {};
+	for (uint32_t p = 0; p < 64u; p++) {
+		t.e[p] = bc7_part_entry(2, 2u, p);
+		t.e[64u + p] = bc7_part_entry(2, 3u, p);
+		t.e[128u + p] = bc7_part_entry(3, 2u, p);
+		if (p < 16u) t.e[192u + p] = bc7_part_entry(3, 3u, p);
+	}
+	t.e[208] = bc7_part_entry(1, 2u, 0u); t.e[209] = bc7_part_entry(1, 3u, 0u); t.e[210] = bc7_part_entry(1, 4u, 0u);
+	return t;
+}
+__constant__ Bc7PartTable kBc7PartTable = bc7_part_table();
+
+// ---- per-mode record ------------------------------------------------------------------------------------
+constexpr uint32_t kBc7RowBytes = 1024u;	// LDS stride between a lane's consecutive block dwords ([row][lane], 256 lanes)
+struct alignas(16) Bc7Rec {
+	uint32_t pos_part, pb, pos_rot, rb;			// header fields of the first dword
+	uint32_t part_base, cb, ab, ns;				// part_base: BYTE offset of the mode's section of the partition table
+	uint32_t row_r, row_g, row_b, row_a;			// LDS row byte offset of the dword a channel's fields start in
+	uint32_t pos_r, pos_g, pos_b, pos_a;			// their bit positions (v_alignbit_b32 uses the low 5 bits)
+	uint32_t row_p, pos_p, p_word_mask, up_c;		// P-bits; QUIRK A-2 mask; colour shift-up 8 - cb
+	uint32_t down_c, up_ba, down_ba, pconst_rg;		// packed per-16-bit-lane shift amounts; P-bit place in (R,G)
+	uint32_t pconst_ba, set_ba, pidx0, pidx1;		// P-bit place in (B,A); alpha = 255 for modes 0-3; P-bit of endpoint e
+	uint32_t pidx2, pidx3, pidx4, pidx5;
+	uint32_t row_c, pos_c, ibc, imask_c;			// colour index stream
+	uint32_t wmul_c, wadd_c, himask0_c, two;		// weight = byte 2 of index * mul + add; texel 0's anchor bit; has a second stream
+	uint32_t row_a2, pos_a2, iba, imask_a;			// alpha index stream (modes 4, 5)
+	uint32_t wmul_a, wadd_a, himask0_a, half_a;
+	uint32_t sel_ba, mode, pad0, pad1;			// v_perm selector building (colour weight, alpha weight)
 };
-constexpr uint32_t bc7_weight_mul(uint32_t bits) { return bits == 2 ? 1398144u : (bits == 3 ? 599232u : 279680u); }
-constexpr uint32_t bc7_weight_add(uint32_t bits) { return bits == 2 ? 21846u : (bits == 3 ? 28089u : 30590u); }
-constexpr Bc7Layout bc7_layout(uint32_t mode, uint32_t desc) {
-	const uint32_t ns = desc & 3u, pb = (desc >> 2) & 7u, rb = (desc >> 5) & 3u, isb = (desc >> 7) & 1u;
-	const uint32_t cb = (desc >> 8) & 7u, ab = (desc >> 11) & 15u, epb = (desc >> 15) & 1u, spb = (desc >> 16) & 1u;
-	const uint32_t ib = (desc >> 17) & 7u, ib2 = (desc >> 20) & 3u;
-	Bc7Layout L = {};
-	L.pos_part = mode + 1u; L.pb = pb;
-	L.pos_rot = L.pos_part + pb; L.rb = rb;
-	L.pos_isel = L.pos_rot + rb; L.isb = isb;
-	const uint32_t chan = 2u * ns * cb;
-	L.pos_r = L.pos_isel + isb; L.pos_g = L.pos_r + chan; L.pos_b = L.pos_g + chan; L.pos_a = L.pos_b + chan;
-	L.pos_p = L.pos_a + 2u * ns * ab;
-	L.pos_idx = L.pos_p + epb * 2u * ns + spb * ns;
-	L.pos_idx2 = L.pos_idx + 16u * ib - ns;
-	L.cb = cb; L.ab = ab;
-	for (uint32_t e = 0; e < 6u; e++) L.off[e] = e * cb;
-	for (uint32_t e = 0; e < 4u; e++) L.offa[e] = e * ab;
-	L.has_p = epb | spb; L.epb = epb;
-	L.p_word_mask = mode == 6u ? 1u : 0xFFFFFFFFu;
-	L.p_double = (spb && !epb) ? 0xFFFFFFFFu : 0u;
-	const uint32_t cprec = cb + L.has_p, aprec = ab + epb;
-	L.c_up = 8u - cprec; L.c_down = (2u * cprec - 8u) & 31u;
-	L.c_keep = 0x010101u * ((1u << L.c_up) - 1u);
-	L.a_up = (8u - aprec) & 31u; L.a_down = (2u * aprec - 8u) & 31u;
-	L.alpha_keep = mode < 4u ? 0u : 0xFFFFFFFFu; L.alpha_set = mode < 4u ? 0xFF000000u : 0u;
-	L.ns = ns; L.part_base = ns == 3u ? 64u : 0u; L.ib = ib; L.ib2 = ib2;
-	L.w_mul = bc7_weight_mul(ib); L.w_add = bc7_weight_add(ib);
-	L.w2_mul = bc7_weight_mul(ib2); L.w2_add = bc7_weight_add(ib2);
+static_assert(sizeof(Bc7Rec) == 208, "record is fetched with 16-byte LDS reads; 52-dword stride keeps records on disjoint banks");
+constexpr int kBc7Recs = 9;
+
+constexpr Bc7Rec bc7_rec(uint32_t mode, bool isel) {
+	const Bc7ModeDesc m = kBc7Modes[mode];
+	Bc7Rec L = {};
+	L.mode = mode;
+	L.pos_part = mode + 1u; L.pb = m.pb;
+	L.pos_rot = L.pos_part + m.pb; L.rb = m.rb;
+	const uint32_t pos_isel = L.pos_rot + m.rb;
+	const uint32_t chan = 2u * m.ns * m.cb;
+	const uint32_t pos_r = pos_isel + m.isb, pos_g = pos_r + chan, pos_b = pos_g + chan, pos_a = pos_b + chan;
+	const uint32_t pos_p = pos_a + 2u * m.ns * m.ab;
+	const uint32_t pos_idx = pos_p + m.epb * 2u * m.ns + m.spb * m.ns;
+	const uint32_t pos_idx2 = pos_idx + 16u * m.ib - m.ns;
+	L.cb = m.cb; L.ab = m.ab; L.ns = m.ns;
+	L.part_base = (uint32_t)sizeof(Bc7PartEntry) *
+		(m.ns == 1u ? 208u + ((isel ? m.ib2 : m.ib) - 2u) : (m.ns == 2u ? (m.ib == 2u ? 0u : 64u) : (m.ib == 2u ? 128u : 192u)));
+	L.row_r = (pos_r >> 5) * kBc7RowBytes; L.row_g = (pos_g >> 5) * kBc7RowBytes;
+	L.row_b = (pos_b >> 5) * kBc7RowBytes; L.row_a = (pos_a >> 5) * kBc7RowBytes;
+	L.pos_r = pos_r; L.pos_g = pos_g; L.pos_b = pos_b; L.pos_a = pos_a;
+	L.row_p = (pos_p >> 5) * kBc7RowBytes; L.pos_p = pos_p;
+	L.p_word_mask = mode == 6u ? 1u : 0xFFFFFFFFu;			// QUIRK A-2 (decompress-bptc.c:142-146)
+	// 8-bit expansion of a cb-bit value v with optional P-bit p (decompress-bptc.c:136-180):
+	//   (v << (8 - cb)) | (p << (7 - cb)) | (v >> (cb + cprec - 8)),  cprec = cb + has_p
+	const uint32_t has_p = m.epb | m.spb, cprec = m.cb + has_p, aprec = m.ab + m.epb;
+	const uint32_t up_c = 8u - m.cb, down_c = m.cb + cprec - 8u;
+	const uint32_t up_a = m.ab ? 8u - m.ab : 0u, down_a = m.ab ? m.ab + aprec - 8u : 0u;
+	L.up_c = up_c;
+	L.down_c = down_c * 0x00010001u;
+	L.up_ba = up_c | (up_a << 16);
+	L.down_ba = down_c | (down_a << 16);
+	const uint32_t pc = has_p ? 1u << (7u - m.cb) : 0u, pa = (m.ab && m.epb) ? 1u << (7u - m.ab) : 0u;
+	L.pconst_rg = pc * 0x00010001u;
+	L.pconst_ba = pc | (pa << 16);
+	L.set_ba = m.ab ? 0u : 0x00FF0000u;				// modes 0-3 are opaque (:176-179)
+	// P-bit of endpoint e: its own (epb), its subset's (spb, mode 1), none (pconst = 0)
+	const uint32_t sh = m.spb ? 1u : 0u;
+	L.pidx0 = 0u >> sh; L.pidx1 = 1u >> sh; L.pidx2 = 2u >> sh; L.pidx3 = 3u >> sh; L.pidx4 = 4u >> sh; L.pidx5 = 5u >> sh;
+	// index streams (:401-480): primary 16*ib - ns bits, then (modes 4/5) the secondary one; the colour stream is
+	// the primary one unless the index-selection bit swaps them (:374-375, 452-480)
+	const bool two = m.ib2 != 0u;
+	const uint32_t ibc = (two && isel) ? m.ib2 : m.ib, iba = two ? (isel ? m.ib : m.ib2) : m.ib;
+	const uint32_t pos_c = (two && isel) ? pos_idx2 : pos_idx, pos_a2 = two ? (isel ? pos_idx : pos_idx2) : 0u;
+	L.row_c = (pos_c >> 5) * kBc7RowBytes; L.pos_c = pos_c; L.ibc = ibc; L.imask_c = (1u << ibc) - 1u;
+	L.wmul_c = bptc_weight_mul(ibc); L.wadd_c = bptc_weight_add(ibc);
+	L.himask0_c = 0xFFFFFFFFu << (ibc - 1u);
+	L.two = two ? 1u : 0u;
+	L.row_a2 = (pos_a2 >> 5) * kBc7RowBytes; L.pos_a2 = pos_a2; L.iba = iba; L.imask_a = (1u << iba) - 1u;
+	L.wmul_a = bptc_weight_mul(iba); L.wadd_a = bptc_weight_add(iba);
+	L.himask0_a = 0xFFFFFFFFu << (iba - 1u);
+	L.half_a = 8u * iba - 1u;
+	// (colour weight, alpha weight) in 16-bit lanes from byte 2 of the two mads; blocks without a second stream
+	// use the colour weight twice
+	L.sel_ba = two ? 0x0C060C02u : 0x0C020C02u;
 	return L;
 }
-constexpr uint32_t kBc7Desc[8] = {
-	//       subsets part rot isel colour alpha endpoint-P shared-P index index2
-	bc7_desc(3, 4, 0, 0, 4, 0, 1, 0, 3, 0), bc7_desc(2, 6, 0, 0, 6, 0, 0, 1, 3, 0), bc7_desc(3, 6, 0, 0, 5, 0, 0, 0, 2, 0),
-	bc7_desc(2, 6, 0, 0, 7, 0, 1, 0, 2, 0), bc7_desc(1, 0, 2, 1, 5, 6, 0, 0, 2, 3), bc7_desc(1, 0, 2, 0, 7, 8, 0, 0, 2, 2),
-	bc7_desc(1, 0, 0, 0, 7, 7, 1, 0, 4, 0), bc7_desc(2, 6, 0, 0, 5, 5, 1, 0, 2, 0) };
-__constant__ Bc7Layout kBc7Layouts[8] = {
-	bc7_layout(0, kBc7Desc[0]), bc7_layout(1, kBc7Desc[1]), bc7_layout(2, kBc7Desc[2]), bc7_layout(3, kBc7Desc[3]),
-	bc7_layout(4, kBc7Desc[4]), bc7_layout(5, kBc7Desc[5]), bc7_layout(6, kBc7Desc[6]), bc7_layout(7, kBc7Desc[7]),
-};
-static_assert(sizeof(Bc7Layout) % 16 == 0, "record is fetched with 16-byte LDS reads");
+struct Bc7RecTable { Bc7Rec r[kBc7Recs]; };
+constexpr Bc7RecTable bc7_rec_table() {
+	Bc7RecTable t = {};
+	for (uint32_t m = 0; m < 8u; m++) t.r[m] = bc7_rec(m, false);
+	t.r[8] = bc7_rec(4u, true);
+	return t;
+}
+__constant__ Bc7RecTable kBc7RecTable = bc7_rec_table();
+constexpr Bc7RecTable kBc7RecTableCx = bc7_rec_table();
 
-// workgroup copies in LDS (dev_common.h: prepare_tables).  anchor_p1[i] = kAnchorWords[i] | kPartition1Bit[i] << 16
-struct BptcTables { uint32_t part2[128]; uint32_t anchor_p1[64]; Bc7Layout layout[8]; };
+// v_perm_b32 selectors gathering the high bytes of the four 16-bit sums (R byte 1, G 3, B 5, A 7), with the
+// mode 4/5 rotation that swaps A with R/G/B (:497-508)
+__constant__ uint32_t kBc7Gather[4] = { 0x07050301u, 0x01050307u, 0x03050701u, 0x05070301u };
+
+// ---- LDS: one struct at a 16 KiB-aligned address -----------------------------------------------------------------------
+// subset rows first (row s of lane l at 4096*s + 16*l: bits 12-13 of a lane's base are clear, so the row address
+// of a texel is bitop3((pword pre-shifted) & 0x3000 | base)); the fourth 4 KiB slot and what follows hold the
+// workgroup tables and the per-lane block dwords.
 #if defined(__HIPCC__)
-DH BptcTables &bptc_tables() { __shared__ BptcTables t; return t; }
-DH void bptc_prepare(bool with_layouts) {
-	BptcTables &t = bptc_tables();
+struct Bc7Lds {
+	uint4 subset[3][256];			// per-lane blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba}
+	Bc7Rec rec[kBc7Recs];
+	uint32_t gather[4];
+	Bc7PartEntry part[kBc7PartEntries];
+	uint32_t bits[6][256];			// per-lane block dwords; rows 4, 5 stay zero (bits beyond 127)
+};
+static_assert(sizeof(Bc7Lds) <= 27306, "six workgroups per CU");
+DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
+DH void bc7_prepare() {
+	Bc7Lds &s = bc7_lds();
 	const uint32_t k = threadIdx.x;
-	if (k < 128u) t.part2[k] = kPartition2Bit[k];
-	else if (k < 192u) t.anchor_p1[k - 128u] = (uint32_t)kAnchorWords[k - 128u] | ((uint32_t)kPartition1Bit[k - 128u] << 16);
-	if (with_layouts) {
-		constexpr uint32_t kWords = 8u * sizeof(Bc7Layout) / 4u;
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(kBc7Layouts);
-		uint32_t *dst = reinterpret_cast<uint32_t *>(t.layout);
+	{
+		constexpr uint32_t kWords = sizeof(Bc7RecTable) / 4u;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc7RecTable);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(s.rec);
 		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
 	}
+	{
+		constexpr uint32_t kWords = sizeof(Bc7PartTable) / 4u;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc7PartTable);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(s.part);
+		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
+	}
+	if (k < 4u) s.gather[k] = kBc7Gather[k];
+	s.bits[4][k] = 0u; s.bits[5][k] = 0u;
 	__syncthreads();
 }
-DH uint32_t bptc_part2(uint32_t i) { return bptc_tables().part2[i]; }
-DH uint32_t bptc_anchor_p1(uint32_t i) { return bptc_tables().anchor_p1[i]; }
-DH const Bc7Layout &bptc_layout(uint32_t m) {
-	// one opaque byte offset per lane: the record's fields then come as immediate offsets of a few wide LDS
-	// reads (left to itself the compiler rebuilds mode * sizeof + field offset with a v_mad per field)
-	uint32_t off = m * (uint32_t)sizeof(Bc7Layout);
-	asm("" : "+v"(off));
-	return *reinterpret_cast<const Bc7Layout *>(reinterpret_cast<const char *>(bptc_tables().layout) + off);
-}
-#else
-DH void bptc_prepare(bool) {}
-DH uint32_t bptc_part2(uint32_t i) { return kPartition2Bit[i]; }
-DH uint32_t bptc_anchor_p1(uint32_t i) { return (uint32_t)kAnchorWords[i] | ((uint32_t)kPartition1Bit[i] << 16); }
-DH const Bc7Layout &bptc_layout(uint32_t m) { return kBc7Layouts[m]; }
 #endif
 
-// weight(index) for a per-lane index width: (64*i + d/2) / d as multiply-shift (dev_common.h)
-struct WeightParams { uint32_t half, magic; };
-DH WeightParams weight_params(uint32_t bits) {
-	WeightParams w;
-	w.half = ((1u << bits) - 1u) >> 1;
-	w.magic = bits == 2 ? 21846u : (bits == 3 ? 9363u : 4370u);
-	return w;
+// the per-lane view of that storage; the host emulation (tests/host_emul) keeps it in plain arrays
+struct Bc7Lane {
+#if defined(__HIPCC__)
+	uint32_t bits_base, subset_base;	// LDS byte addresses of this lane's column
+	DH Bc7Lane() {
+		Bc7Lds &s = bc7_lds();
+		bits_base = (uint32_t)(uintptr_t)&s.bits[0][threadIdx.x];
+		subset_base = (uint32_t)(uintptr_t)&s.subset[0][threadIdx.x];
+	}
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(3))) u32x4 lds_u4;
+	DH void put_bits(uint4 blk) const {
+		lds_u32 *p = (lds_u32 *)(uintptr_t)bits_base;
+		p[0] = blk.x; p[256] = blk.y; p[512] = blk.z; p[768] = blk.w;
+	}
+	// bits [pos, pos+32) of the block; row = (pos >> 5) * kBc7RowBytes
+	DH uint32_t field(uint32_t row, uint32_t pos) const {
+		const lds_u32 *p = (const lds_u32 *)(uintptr_t)(bits_base + row);
+		return __builtin_amdgcn_alignbit(p[256], p[0], pos);
+	}
+	// bits [pos, pos+32) and [pos+32, pos+64)
+	DH void field64(uint32_t row, uint32_t pos, uint32_t &lo, uint32_t &hi) const {
+		const lds_u32 *p = (const lds_u32 *)(uintptr_t)(bits_base + row);
+		const uint32_t d0 = p[0], d1 = p[256], d2 = p[512];
+		lo = __builtin_amdgcn_alignbit(d1, d0, pos);
+		hi = __builtin_amdgcn_alignbit(d2, d1, pos);
+	}
+	DH void put_subset(int s, uint4 v) const { ((lds_u4 *)(uintptr_t)subset_base)[s * 256] = u32x4{ v.x, v.y, v.z, v.w }; }
+	// sel: any word with the subset number at bits 12-13
+	DH uint4 get_subset(uint32_t sel) const {
+		const u32x4 v = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel, 0x3000u, subset_base, 0xEA);
+		return uint4{ v.x, v.y, v.z, v.w };
+	}
+	static DH const Bc7Rec &rec(uint32_t r) {
+		uint32_t off = r * (uint32_t)sizeof(Bc7Rec);
+		asm("" : "+v"(off));	// one opaque byte offset: the fields then come as immediate offsets of a few wide LDS reads
+		return *reinterpret_cast<const Bc7Rec *>(reinterpret_cast<const char *>(bc7_lds().rec) + off);
+	}
+	static DH const Bc7PartEntry &part(uint32_t byte_offset) {
+		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().part) + byte_offset);
+	}
+	static DH uint32_t gather(uint32_t rot) { return bc7_lds().gather[rot]; }
+#else
+	uint32_t bits[6];
+	uint4 subset[3];
+	DH Bc7Lane() { for (int k = 0; k < 6; k++) bits[k] = 0u; }
+	DH void put_bits(uint4 blk) { bits[0] = blk.x; bits[1] = blk.y; bits[2] = blk.z; bits[3] = blk.w; }
+	DH uint32_t field(uint32_t row, uint32_t pos) const {
+		const uint32_t k = row / kBc7RowBytes;
+		return __builtin_amdgcn_alignbit(bits[k + 1], bits[k], pos);
+	}
+	DH void field64(uint32_t row, uint32_t pos, uint32_t &lo, uint32_t &hi) const {
+		const uint32_t k = row / kBc7RowBytes;
+		lo = __builtin_amdgcn_alignbit(bits[k + 1], bits[k], pos);
+		hi = __builtin_amdgcn_alignbit(bits[k + 2], bits[k + 1], pos);
+	}
+	DH void put_subset(int s, uint4 v) { subset[s] = v; }
+	DH uint4 get_subset(uint32_t sel) const { return subset[(sel >> 12) & 3u]; }
+	static DH const Bc7Rec &rec(uint32_t r) { return kBc7RecTable.r[r]; }
+	static DH const Bc7PartEntry &part(uint32_t byte_offset) { return kBc7PartTable.e[byte_offset / sizeof(Bc7PartEntry)]; }
+	static DH uint32_t gather(uint32_t rot) { return kBc7Gather[rot]; }
+#endif
+};
+
+// FIXED >= 0: the record is a compile-time constant (every lane of the wave is known to use record FIXED)
+template <int FIXED, bool CHECKED>
+DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
+	constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
+	const Bc7Rec &L = FIXED >= 0 ? kFixed : Bc7Lane::rec(rec_index);
+	const uint32_t mode = L.mode;
+	if (CHECKED) {							// decompress-bptc.c:363-369
+		if (!(mode_mask & (1u << mode))) return false;
+		if (mode >= 4u && (flags & kFlagOpaqueOnly)) return false;
+		if (mode < 4u && (flags & kFlagNonOpaqueOnly)) return false;
+	}
+	Bc7Lane lane;
+	lane.put_bits(blk);
+
+	// header fields all lie in the first 14 bits
+	const uint32_t part = ubfe(blk.x, L.pos_part, L.pb);
+	const uint32_t rot = ubfe(blk.x, L.pos_rot, L.rb);
+	const Bc7PartEntry &pe = Bc7Lane::part(DETEX_UMUL24(part, (uint32_t)sizeof(Bc7PartEntry)) + L.part_base);
+	const uint32_t gather = Bc7Lane::gather(rot);
+
+	// wave-uniform trimming: endpoints of subsets no lane of the wave has are not expanded, alpha fields are
+	// skipped in waves of opaque modes, the second index stream in waves without modes 4/5 (the uniform-random
+	// stream has all of them in nearly every wave; encoder output mostly does not)
+	const uint32_t wave_subsets = FIXED >= 0 ? kFixed.ns
+		: (__builtin_amdgcn_ballot_w64(L.ns == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(L.ns == 2u) ? 2u : 1u));
+	const bool wave_alpha = FIXED >= 0 ? kFixed.ab != 0u : __builtin_amdgcn_ballot_w64(mode >= 4u) != 0;
+	const bool any_two = FIXED >= 0 ? kFixed.two != 0u : __builtin_amdgcn_ballot_w64(L.two != 0u) != 0;
+
+	// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values), then the P-bits (:74-132)
+	const uint32_t wr = lane.field(L.row_r, L.pos_r), wg = lane.field(L.row_g, L.pos_g), wb = lane.field(L.row_b, L.pos_b);
+	const uint32_t wa = wave_alpha ? lane.field(L.row_a, L.pos_a) : 0u;
+	const uint32_t pw = lane.field(L.row_p, L.pos_p) & L.p_word_mask;
+	const uint32_t cb = L.cb, ab = L.ab;
+	const uint32_t pidx[6] = { L.pidx0, L.pidx1, L.pidx2, L.pidx3, L.pidx4, L.pidx5 };
+	uint32_t x_rg[6], x_ba[6];
+	uint32_t off = 0u, offa = 0u;
+#pragma unroll
+	for (int e = 0; e < 6; e++) {
+		if ((uint32_t)(e >> 1) >= wave_subsets) break;
+		// straight into the blend's 16-bit lanes: (R, G) and (B, A)
+		const uint32_t rg = (ubfe(wg, off, cb) << 16) | ubfe(wr, off, cb);
+		uint32_t ba = ubfe(wb, off, cb);
+		if (e < 4) ba |= ubfe(wa, offa, ab) << 16;		// modes with alpha have at most two subsets; ab = 0 reads 0
+		const uint32_t pm = (uint32_t)sbfe(pw, pidx[e], 1u);			// 0 / ~0: this endpoint's P-bit
+		x_rg[e] = or3(rg << L.up_c, pk_lshr_v(L.down_c, rg), pm & L.pconst_rg);
+		x_ba[e] = or3(pk_lshl_v(L.up_ba, ba), pk_lshr_v(L.down_ba, ba), and_or(pm, L.pconst_ba, L.set_ba));
+		off = FIXED >= 0 ? off + cb : opaque(off + cb);		// running sums as plain adds (opaque: not re-derived as e * cb with shifts)
+		offa = FIXED >= 0 ? offa + ab : opaque(offa + ab);
+	}
+	// With e0, e1 in 0..255 and w in 0..64 the reference's ((64-w)*e0 + w*e1 + 32) >> 6 (:182-193) equals the
+	// high byte of 256*e0 + 128 + 4*w*(e1 - e0) (range 128 .. 65408: fits a 16-bit lane, exact mod 2^16), so a
+	// texel is two v_pk_mad_u16 and one v_perm_b32 that gathers the four high bytes.
+#pragma unroll
+	for (int s = 0; s < 3; s++) {
+		if ((uint32_t)s >= wave_subsets) break;
+		uint4 row;
+		row.x = (x_rg[2 * s] << 8) | 0x00800080u;
+		row.y = (x_ba[2 * s] << 8) | 0x00800080u;
+		row.z = pk_lshl_v(0x00020002u, pk_sub_u16(x_rg[2 * s + 1], x_rg[2 * s]));	// 4*(e1-e0) per 16-bit lane (mod 2^16)
+		row.w = pk_lshl_v(0x00020002u, pk_sub_u16(x_ba[2 * s + 1], x_ba[2 * s]));
+		lane.put_subset(s, row);
+	}
+
+	// subset number of texel i at bits 12-13 of (p_lo >> 2i) for i < 6, of (pword >> (2i - 12)) above: right shifts only
+	const uint32_t pword = pe.pword, p_lo = pword << 12;
+
+	// Colour index stream: 64 stream bits from its start; texels 0-7 consume `half` of them, texels 8-15 start
+	// there.  Each window then gets the anchors' absent top bits inserted as zeros (w + (w & himask) doubles the
+	// part of w at and above the insertion point), after which texel k of a window sits at bit k*ib.
+	uint32_t c0, c1;
+	lane.field64(L.row_c, L.pos_c, c0, c1);
+	uint32_t cw = c0, cw_hi = __builtin_amdgcn_alignbit(c1, c0, pe.half);
+	cw += cw & L.himask0_c;
+	cw += cw & pe.m_lo1;
+	cw += cw & pe.m_lo2;
+	cw_hi += cw_hi & pe.m_hi1;
+	cw_hi += cw_hi & pe.m_hi2;
+	const uint32_t ibc = L.ibc, imask_c = L.imask_c, wmul_c = L.wmul_c, wadd_c = L.wadd_c;
+
+	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
+	if (any_two) {
+		// alpha stream (modes 4/5: one subset, the only anchor is texel 0)
+		uint32_t a0, a1;
+		lane.field64(L.row_a2, L.pos_a2, a0, a1);
+		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, L.half_a);
+		aw += aw & L.himask0_a;
+		const uint32_t iba = L.iba, imask_a = L.imask_a, wmul_a = L.wmul_a, wadd_a = L.wadd_a, sel_ba = L.sel_ba;
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			if (i == 8) { cw = cw_hi; aw = aw_hi; }
+			const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;	// weight = byte 2
+			cw >>= ibc;
+			const uint32_t ta = DETEX_UMUL24(aw & imask_a, wmul_a) + wadd_a;
+			aw >>= iba;
+			const uint4 s = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12));
+			d[i] = perm(pk_mad_u16(s.w, perm(ta, tc, sel_ba), s.y), pk_mad_u16_bhi(s.z, tc, s.x), gather);
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			if (i == 8) cw = cw_hi;
+			const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;
+			cw >>= ibc;
+			const uint4 s = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12));
+			d[i] = perm(pk_mad_u16_bhi(s.w, tc, s.y), pk_mad_u16_bhi(s.z, tc, s.x), gather);
+		}
+	}
+	return true;
 }
-DH uint32_t weight_of(uint32_t index, const WeightParams &w) { return DETEX_UMUL24((index << 6) + w.half, w.magic) >> 16; }
 
-// packed 2 x u16 arithmetic in one VGPR (v_pk_mad_u16 / v_pk_sub_u16): lanes wrap mod 2^16
-typedef uint16_t pk16 __attribute__((vector_size(4)));
-DH pk16 as_pk16(uint32_t v) { pk16 r; __builtin_memcpy(&r, &v, 4); return r; }
-DH uint32_t from_pk16(pk16 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
-DH uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return from_pk16(as_pk16(a) * as_pk16(b) + as_pk16(c)); }
-DH uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return from_pk16(as_pk16(a) - as_pk16(b)); }
-
-// One subset's endpoint pair prepared for blending.  With e0, e1 in 0..255 and w in 0..64 the
-// reference's ((64-w)*e0 + w*e1 + 32) >> 6 (decompress-bptc.c:182-193) equals the high byte of
-//     256*e0 + 128 + 4*w*(e1 - e0)          (range 128 .. 65408: fits a 16-bit lane, exact mod 2^16)
-// so a texel is two v_pk_mad_u16 (R,G and B,A lanes) and one v_perm_b32 that gathers the four
-// high bytes (and applies the mode 4/5 channel rotation for free).
-struct BlendPair { uint32_t base_rg, base_ba, diff_rg, diff_ba; };
-DH BlendPair blend_pair(uint32_t e0, uint32_t e1) {
-	const uint32_t rg0 = perm(0u, e0, 0x0C010C00u), ba0 = perm(0u, e0, 0x0C030C02u);	// zero-extended channel pairs
-	const uint32_t rg1 = perm(0u, e1, 0x0C010C00u), ba1 = perm(0u, e1, 0x0C030C02u);
-	BlendPair p;
-	p.base_rg = (rg0 << 8) | 0x00800080u;
-	p.base_ba = (ba0 << 8) | 0x00800080u;
-	p.diff_rg = pk_sub_u16(rg1, rg0);
-	p.diff_ba = pk_sub_u16(ba1, ba0);
-	return p;
+// record of a block: its mode, +4 for mode 4 with the index-selection bit (block bit 7) set
+DH uint32_t bc7_record_index(uint32_t first_dword) {
+	const uint32_t mode = (uint32_t)__builtin_ctz(first_dword | 0x100u);
+	return (first_dword & 0x9Fu) == 0x90u ? 8u : mode;		// ...1 0000 with bit 7 set
 }
 
-// Weight of an n-bit index as one multiply-add: t = (64*i + d/2) * ceil(65536/d) < 2^24 and the
-// weight is byte 2 of t (bptc-tables.c aWeight2/3/4 in closed form, proven in tests/test_host_logic.py).
-struct WeightMad { uint32_t mul, add; };
-DH WeightMad weight_mad(uint32_t bits) {
-	WeightMad w;
-	w.mul = bits == 2 ? 1398144u : (bits == 3 ? 599232u : 279680u);
-	w.add = bits == 2 ? 21846u : (bits == 3 ? 28089u : 30590u);
-	return w;
-}
-
-// FIXED_MODE >= 0 instantiates the decoder for one mode with every layout parameter a compile-time
-// constant (used by wave-uniform fast paths); FIXED_MODE = -1 is the per-lane data-driven form.
-// IMPL selects the texel stage (A/B):
-//   0  subset endpoints picked per texel with v_bfi_b32 chains (registers only)
-//   1  subset endpoints kept in per-lane LDS rows, one ds_read_b128 per texel; colour / alpha index
-//      streams (instead of primary / secondary + per-texel swaps); weights by one v_mad_u32_u24
-//   2  as 1, and block fields are fetched from an LDS copy of the block (two dwords + v_alignbit)
-template <int FIXED_MODE, int IMPL = 2> struct DecBPTCMode {
+// UNIFORM: waves whose blocks all share one record run a copy specialised for it (kernels that are not on the
+// throughput path -- clipped geometry, the checked per-block batch -- instantiate the plain form to bound code size)
+template <bool UNIFORM> struct DecBPTCT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
-	static DH void prepare() { bptc_prepare(true); }
-
+	static constexpr bool kPersistent = true;	// sizeable LDS tables: workgroups loop over tiles (kernels.h)
+#if defined(__HIPCC__)
+	static DH void prepare() { bc7_prepare(); }
+#endif
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
-		const uint32_t low = blk.x & 0xFFu;
-		if (low == 0) return false;				// reserved (decompress-bptc.c:229-237, 361)
-		const uint32_t mode = FIXED_MODE >= 0 ? (uint32_t)FIXED_MODE : (uint32_t)__builtin_ctz(low);
-		if (CHECKED) {						// :363-369
-			if (!(mode_mask & (1u << mode))) return false;
-			if (mode >= 4 && (flags & kFlagOpaqueOnly)) return false;
-			if (mode < 4 && (flags & kFlagNonOpaqueOnly)) return false;
-		}
-		// the mode's layout record: compile-time for a fixed mode, one LDS record for a per-lane mode
-		constexpr Bc7Layout kFixed = bc7_layout(FIXED_MODE >= 0 ? FIXED_MODE : 0, kBc7Desc[FIXED_MODE >= 0 ? FIXED_MODE : 0]);
-		const Bc7Layout &L = FIXED_MODE >= 0 ? kFixed : bptc_layout(mode);
-		const uint32_t ns = L.ns, cb = L.cb, ab = L.ab, epb = L.epb, has_p = L.has_p, ib = L.ib, ib2 = L.ib2;
-		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
-		// IMPL 2: the block's dwords as per-lane LDS rows (rows 4, 5 read as zero: bits beyond 127)
-		LaneRows<uint32_t, IMPL == 2 ? 6 : 1, 71> rows;
-		if (IMPL == 2) {
-			rows.put(0, blk.x); rows.put(1, blk.y); rows.put(2, blk.z); rows.put(3, blk.w); rows.put(4, 0u); rows.put(5, 0u);
-		}
-		auto field32 = [&](uint32_t at) -> uint32_t {
-			if (IMPL != 2) return extract32(b, at);
-			const uint32_t k = at >> 5;
-			return __builtin_amdgcn_alignbit(rows.get(k + 1u), rows.get(k), at);
-		};
-
-		// header fields all lie in the first 14 bits
-		const uint32_t part = ubfe(blk.x, L.pos_part, L.pb);
-		const uint32_t rot = ubfe(blk.x, L.pos_rot, L.rb);
-		const uint32_t isel = ubfe(blk.x, L.pos_isel, L.isb);
-
-		// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values) -- :74-132
-		const uint32_t wr = field32(L.pos_r), wg = field32(L.pos_g), wb = field32(L.pos_b), wa = field32(L.pos_a);
-		uint32_t pw = field32(L.pos_p) & L.p_word_mask;	// P-bits; QUIRK A-2: mode 6 keeps only the first (:142-146)
-		const uint32_t pos = L.pos_idx;
-
-		// expand to 8 bits: append the P-bit, shift the MSB to bit 7, replicate the top bits (:136-180)
-		const uint32_t c_up = L.c_up, c_down = L.c_down, c_keep = L.c_keep, a_up = L.a_up, a_down = L.a_down;
-		// P-bit of endpoint e at bit e: per-endpoint P-bits as stored, a shared P-bit (mode 1) doubled
-		const uint32_t pw_e = bfi(L.p_double, ((pw & 1u) * 3u) | ((pw & 2u) * 6u), pw) & (0u - has_p);
-		// subsets actually present in this wave (wave-uniform): endpoints of absent subsets are not expanded.  The
-		// uniform-random stream always has three-subset blocks (modes 0, 2) in every wave; encoder output mostly does not.
-		const uint32_t wave_subsets = FIXED_MODE >= 0 ? L.ns : (IMPL == 0 ? 3u
-			: (__builtin_amdgcn_ballot_w64(ns == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(ns == 2u) ? 2u : 1u)));
-		// likewise the alpha fields: modes 0-3 are opaque
-		const bool wave_alpha = FIXED_MODE >= 0 ? FIXED_MODE >= 4 : (IMPL == 0 || __builtin_amdgcn_ballot_w64(mode >= 4u) != 0);
-		uint32_t ep[6] = {};
-#pragma unroll
-		for (int e = 0; e < 6; e++) {
-			if ((uint32_t)(e >> 1) >= wave_subsets) break;
-			const uint32_t off = L.off[e];
-			// (three-input logic goes through v_bitop3_b32 -- dev_common.h: and_or / or3 -- at 2.5 cycles instead of 4.4)
-			uint32_t x = or3(ubfe(wr, off, cb), ubfe(wg, off, cb) << 8, ubfe(wb, off, cb) << 16);
-			const uint32_t p = ubfe(pw_e, e, 1);
-			x = and_or(0u - p, 0x010101u, x << has_p);
-			x = and_or(x >> c_down, c_keep, x << c_up);		// each byte holds cprec bits: nothing crosses a byte
-			uint32_t a = 0xFF000000u;				// :176-179; modes with alpha have at most two subsets
-			if (e < 4 && wave_alpha) {
-				a = ubfe(wa, L.offa[e], ab);
-				a = and_or(p, epb, a << epb);
-				a = ((a << a_up) | (a >> a_down)) << 24;	// bits above the byte fall off the top
-				a = and_or(a, L.alpha_keep, L.alpha_set);	// modes 0-3 are opaque
-			}
-			ep[e] = x | a;
-		}
-
-		// partition + anchors (:391-400)
-		const uint32_t pword = ns == 1u ? 0u : bptc_part2(part + L.part_base);
-		const uint32_t an = bptc_anchor_p1(part);
-		const uint32_t a1 = ns == 2u ? (an & 0xFu) : ubfe(an, 4, 4), a2 = ubfe(an, 8, 4);
-		const uint32_t amask = 1u | (ns >= 2u ? (1u << a1) : 0u) | (ns == 3u ? (1u << a2) : 0u);
-		// gather the high bytes of the four 16-bit sums; rotation swaps A with R/G/B (:497-508)
-		const uint32_t gather = rot == 0u ? 0x07050301u : (rot == 1u ? 0x01050307u : (rot == 2u ? 0x03050701u : 0x05070301u));
-		// index streams, LSB-first: primary (16*ib - ns bits), then, for modes 4/5, the secondary one
-		// (16*ib2 - 1 bits) -- :401-480
-		const uint32_t pos2 = L.pos_idx2;
-		const bool two = ib2 != 0u, swap = two && isel != 0u;
-		const bool any_two = FIXED_MODE >= 0 ? (FIXED_MODE == 4 || FIXED_MODE == 5) : (__builtin_amdgcn_ballot_w64(two) != 0);
-
-		if (IMPL == 0) {
-			const BlendPair s0 = blend_pair(ep[0], ep[1]), s1 = blend_pair(ep[2], ep[3]), s2 = blend_pair(ep[4], ep[5]);
-			uint32_t plo = extract32(b, pos), phi = extract32(b, pos + 32u);
-			uint32_t slo = 0, shi = 0;
-			if (any_two) { slo = extract32(b, pos2); shi = extract32(b, pos2 + 32u); }
-			// colour uses the secondary indices when the index-selection bit is set (:374-375, 452-480)
-			const WeightParams wp_a = weight_params(ib), wp_b = weight_params(two ? ib2 : ib);
-#pragma unroll
-			for (int i = 0; i < 16; i++) {
-				const uint32_t width = ib - ((amask >> i) & 1u);	// anchor texels store one bit less
-				const uint32_t w_a = weight_of(ubfe(plo, 0, width), wp_a);
-				plo = __builtin_amdgcn_alignbit(phi, plo, width);
-				phi >>= width;
-				uint32_t w_rg = DETEX_UMUL24(w_a, 0x00040004u), w_ba = w_rg;	// 4*w in both 16-bit lanes
-				if (any_two) {
-					const uint32_t width2 = (ib2 - (i == 0 ? 1u : 0u)) & 31u;
-					const uint32_t w_b = two ? weight_of(ubfe(slo, 0, width2), wp_b) : w_a;
-					slo = __builtin_amdgcn_alignbit(shi, slo, width2);
-					shi >>= width2;
-					const uint32_t wc = swap ? w_b : w_a, wal = swap ? w_a : w_b;
-					w_rg = DETEX_UMUL24(wc, 0x00040004u);
-					w_ba = (wc | (wal << 16)) << 2;
+		if ((blk.x & 0xFFu) == 0u) return false;		// reserved (decompress-bptc.c:229-237, 361)
+		const uint32_t r = bc7_record_index(blk.x);
+#if defined(__HIPCC__)
+		if (UNIFORM && !CHECKED) {
+			const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+			if (__builtin_amdgcn_ballot_w64(r != r0) == 0) {
+				switch (r0) {
+				case 0: return bc7_decode_with<0, false>(blk, r, mode_mask, flags, d);
+				case 1: return bc7_decode_with<1, false>(blk, r, mode_mask, flags, d);
+				case 2: return bc7_decode_with<2, false>(blk, r, mode_mask, flags, d);
+				case 3: return bc7_decode_with<3, false>(blk, r, mode_mask, flags, d);
+				case 4: return bc7_decode_with<4, false>(blk, r, mode_mask, flags, d);
+				case 5: return bc7_decode_with<5, false>(blk, r, mode_mask, flags, d);
+				case 6: return bc7_decode_with<6, false>(blk, r, mode_mask, flags, d);
+				case 7: return bc7_decode_with<7, false>(blk, r, mode_mask, flags, d);
+				default: return bc7_decode_with<8, false>(blk, r, mode_mask, flags, d);
 				}
-				const uint32_t m1 = bit_to_mask(pword, 2 * i), m2 = bit_to_mask(pword, 2 * i + 1);
-				const uint32_t base_rg = bfi(m2, s2.base_rg, bfi(m1, s1.base_rg, s0.base_rg));
-				const uint32_t base_ba = bfi(m2, s2.base_ba, bfi(m1, s1.base_ba, s0.base_ba));
-				const uint32_t diff_rg = bfi(m2, s2.diff_rg, bfi(m1, s1.diff_rg, s0.diff_rg));
-				const uint32_t diff_ba = bfi(m2, s2.diff_ba, bfi(m1, s1.diff_ba, s0.diff_ba));
-				d[i] = perm(pk_mad_u16(diff_ba, w_ba, base_ba), pk_mad_u16(diff_rg, w_rg, base_rg), gather);
-			}
-			return true;
-		}
-
-		// ---- IMPL 1 / 2 ----
-		// per-subset blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba} as LDS rows of this lane
-		LaneRows<uint4, 3, 72> subsets;
-#pragma unroll
-		for (int s = 0; s < 3; s++) {
-			if ((uint32_t)s >= wave_subsets) break;
-			const uint32_t e0 = ep[2 * s], e1 = ep[2 * s + 1];
-			const uint32_t rg0 = perm(0u, e0, 0x0C010C00u), ba0 = perm(0u, e0, 0x0C030C02u);
-			const uint32_t rg1 = perm(0u, e1, 0x0C010C00u), ba1 = perm(0u, e1, 0x0C030C02u);
-			uint4 row;
-			row.x = (rg0 << 8) | 0x00800080u;
-			row.y = (ba0 << 8) | 0x00800080u;
-			row.z = pk_sub_u16(rg1 << 2, rg0 << 2);		// 4*(e1-e0) per 16-bit lane (mod 2^16)
-			row.w = pk_sub_u16(ba1 << 2, ba0 << 2);
-			subsets.put(s, row);
-		}
-		// colour stream C and alpha stream A: C is the primary stream unless the index-selection bit
-		// swaps them (:374-375, 452-480); only modes 4/5 have an A stream (one subset, anchor = texel 0)
-		const uint32_t sm = cond_to_mask(swap);
-		const uint32_t ibc = bfi(sm, ib2, ib), iba = bfi(sm, ib, ib2);
-		const uint32_t pos_c = bfi(sm, pos2, pos), pos_a = bfi(sm, pos, pos2);
-		// Each stream is read through two 32-bit windows: texels 0-7 consume at most 31 bits (texel 0 is
-		// always an anchor), texels 8-15 start where they ended -- so advancing a stream is one plain shift.
-		const uint32_t half_c = 8u * ibc - (uint32_t)__builtin_popcount(amask & 0xFFu);
-		const uint32_t c_lo = field32(pos_c), c_hi = field32(pos_c + half_c);
-		const WeightMad wm_c = { bfi(sm, L.w2_mul, L.w_mul), bfi(sm, L.w2_add, L.w_add) };
-		// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
-		if (any_two) {
-			const uint32_t half_a = (8u * iba - 1u) & 31u;
-			const uint32_t a_lo = field32(pos_a), a_hi = field32(pos_a + half_a);
-			const WeightMad wm_a = { bfi(sm, L.w_mul, L.w2_mul), bfi(sm, L.w_add, L.w2_add) };
-			const uint32_t sel_ba = two ? 0x0C060C02u : 0x0C020C02u;	// alpha weight from the A stream, or the colour weight again
-			const uint32_t width_a = iba & 31u;
-			uint32_t cw = c_lo, aw = a_lo;
-#pragma unroll
-			for (int i = 0; i < 16; i++) {
-				if (i == 8) { cw = c_hi; aw = a_hi; }
-				const uint32_t width = ibc - ((amask >> i) & 1u);	// anchor texels store one bit less
-				const uint32_t tc = DETEX_UMUL24(ubfe(cw, 0, width), wm_c.mul) + wm_c.add;	// weight = byte 2
-				cw >>= width;
-				const uint32_t wa = i == 0 ? ((iba - 1u) & 31u) : width_a;
-				const uint32_t ta = DETEX_UMUL24(ubfe(aw, 0, wa), wm_a.mul) + wm_a.add;
-				aw >>= wa;
-				const uint4 s = subsets.get(ubfe(pword, 2 * i, 2));
-				d[i] = perm(pk_mad_u16(s.w, perm(ta, tc, sel_ba), s.y), pk_mad_u16(s.z, perm(tc, tc, 0x0C020C02u), s.x), gather);
-			}
-		} else {
-			uint32_t cw = c_lo;
-#pragma unroll
-			for (int i = 0; i < 16; i++) {
-				if (i == 8) cw = c_hi;
-				const uint32_t width = ibc - ((amask >> i) & 1u);
-				const uint32_t tc = DETEX_UMUL24(ubfe(cw, 0, width), wm_c.mul) + wm_c.add;
-				cw >>= width;
-				const uint32_t w = perm(tc, tc, 0x0C020C02u);		// weight in both 16-bit lanes
-				const uint4 s = subsets.get(ubfe(pword, 2 * i, 2));
-				d[i] = perm(pk_mad_u16(s.w, w, s.y), pk_mad_u16(s.z, w, s.x), gather);
 			}
 		}
-		return true;
+#endif
+		return bc7_decode_with<-1, CHECKED>(blk, r, mode_mask, flags, d);
 	}
 };
-using DecBPTC = DecBPTCMode<-1>;
-using DecBPTCRegisterSelect = DecBPTCMode<-1, 0>;
-using DecBPTCRegisterFields = DecBPTCMode<-1, 1>;
+using DecBPTC = DecBPTCT<true>;
+using DecBPTCPlain = DecBPTCT<false>;
 
 }  // namespace detexhip

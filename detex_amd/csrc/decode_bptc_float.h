@@ -14,7 +14,7 @@
 // Reference quirk reproduced: in mode 12 block bit 63 (b0[11]) reads as 0.
 #pragma once
 #include "dev_common.h"
-#include "decode_bptc.h"
+#include "bptc_common.h"
 
 namespace detexhip {
 
@@ -161,12 +161,13 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 };
 
 // workgroup copy of the mode words in LDS (dev_common.h: prepare_tables); the partition / anchor words come
-// from the BPTC tables (decode_bptc.h)
+// from the BPTC tables (bptc_common.h)
 #if defined(__HIPCC__)
 DH Bc6hModeWords *bc6h_mode_words_lds() { __shared__ Bc6hModeWords t[14]; return t; }
 DH void bc6h_prepare() {
 	if (threadIdx.x >= 200u && threadIdx.x < 214u) bc6h_mode_words_lds()[threadIdx.x - 200u] = kBc6hModeWords[threadIdx.x - 200u];
-	bptc_prepare(false);	// ends in the workgroup barrier
+	bptc_anchor_p1_prepare();
+	__syncthreads();
 }
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_mode_words_lds()[mode]; }
 #else

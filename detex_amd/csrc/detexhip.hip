@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <type_traits>
 
@@ -22,8 +23,12 @@
 #include "decode_bptc_float.h"
 #include "kernels.h"
 #include "kernels_extra.h"
-#include "variant_tile4x4.h"
-#include "kernels_sorted.h"
+#ifdef DETEXHIP_AB_VARIANTS
+// rejected A/B kernels: only in the measurement build (make lib-ab), never in the product library
+#include "ab/variant_tile4x4.h"
+#include "ab/decode_bptc_r01.h"
+#include "ab/kernels_sorted.h"
+#endif
 
 using namespace detexhip;
 
@@ -78,13 +83,43 @@ template <class Dec> constexpr int target_class() {
 	return 0;
 }
 
-// alternative decoder implementations selectable for A/B measurements (kernel variant 3)
-template <class Dec> struct AltDecoder { using type = Dec; };
-template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };
-template <> struct AltDecoder<DecBPTC> { using type = DecBPTCRegisterSelect; };
-// second alternative (kernel variant 4)
-template <class Dec> struct AltDecoder2 { using type = Dec; };
-template <> struct AltDecoder2<DecBPTC> { using type = DecBPTCRegisterFields; };
+// decoders whose throughput kernels carry wave-uniform specialisations use the plain form in the kernels that
+// are not on the throughput path (clipped geometry, mip levels), to bound code size
+template <class Dec> struct PlainDecoder { using type = Dec; };
+template <> struct PlainDecoder<DecBPTC> { using type = DecBPTCPlain; };
+
+// workgroups that are resident at once on the current device for this kernel (cached per kernel)
+template <class K> uint32_t resident_workgroups(K kernel) {
+	static std::atomic<uint32_t> cached{ 0 };
+	uint32_t v = cached.load(std::memory_order_relaxed);
+	if (v == 0) {
+		int per_cu = 0, cus = 0, dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0 || cus <= 0)
+			v = 2048;
+		else
+			v = (uint32_t)per_cu * (uint32_t)cus;
+		cached.store(v, std::memory_order_relaxed);
+	}
+	return v;
+}
+template <class Dec, class = void> struct IsPersistent { static constexpr bool value = false; };
+template <class Dec> struct IsPersistent<Dec, std::enable_if_t<Dec::kPersistent>> { static constexpr bool value = true; };
+// one workgroup per 256-block tile, or (Dec::kPersistent) as many as are resident at once, each looping over tiles
+template <class Dec, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
+	if constexpr (IsPersistent<Dec>::value) {
+		const uint32_t r = resident_workgroups(kernel);
+		return tiles < r ? tiles : r;
+	}
+	return tiles;
+}
+
+#ifdef DETEXHIP_AB_VARIANTS
+#include "ab/ab_dispatch.h"
+constexpr int kMaxVariant = 5;
+#else
+constexpr int kMaxVariant = 0;
+#endif
 
 template <class Dec, int EPI> bool fast_geometry(const Geometry &g) {
 	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
@@ -94,43 +129,19 @@ template <class Dec, int EPI> bool fast_geometry(const Geometry &g) {
 }
 
 template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
-	const uint32_t n = g.wb * g.hb;
-	const dim3 grid((n + 255u) / 256u), block(256);
+	const uint32_t n = g.wb * g.hb, tiles = (n + 255u) / 256u;
 	uint8_t *px = static_cast<uint8_t *>(g.pixels);
 	if (fast_geometry<Dec, EPI>(g)) {
-		if (EPI == kEpiNone && g.variant == 1 && Tile4x4<Dec>::kAvailable && (g.wb % 16u) == 0 && (g.hb % 4u) == 0)
-			return Tile4x4<Dec>::launch(g.blocks, px, g.wb, g.hb, g.pitch, g.status, g.stream);
-		if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder<Dec>::type, Dec>) {
-			if (g.variant == 3) {	// A/B: BC6H per-mode switch scatter; BC7 register-select texel stage
-				hipLaunchKernelGGL((decode_linear<typename AltDecoder<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px,
-					g.wb, n, g.pitch, g.status);
-				return hipGetLastError();
-			}
-		}
-		if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder2<Dec>::type, Dec>) {
-			if (g.variant == 4) {	// A/B: BC7 with block fields extracted from registers (no LDS copy of the block)
-				hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px,
-					g.wb, n, g.pitch, g.status);
-				return hipGetLastError();
-			}
-		}
-		if constexpr (ClassSorted<Dec>::kAvailable && Epilogue<EPI, Dec::kPixelBytes>::kRowDwords == 4) {
-			if (g.variant == 5) {	// A/B: mode-sorted waves (kernels_sorted.h) -- measured slower than the all-modes decoder, DESIGN.md section 5
-				hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
-				return hipGetLastError();
-			}
-		}
-		if (EPI == kEpiNone && g.variant == 6) {	// A/B: XCD-contiguous tile order
-			hipLaunchKernelGGL((decode_linear<Dec, kEpiNone, true, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
-			return hipGetLastError();
-		}
-		if (EPI != kEpiNone || g.variant != 2)	// default: non-temporal row stores (43 vs 51 us on BC1 8192^2)
-			hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
-		else
-			hipLaunchKernelGGL((decode_linear<Dec, kEpiNone, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+#ifdef DETEXHIP_AB_VARIANTS
+		hipError_t ab_result;
+		if (g.variant != 0 && ab_launch_linear<Dec, EPI>(g, &ab_result)) return ab_result;
+#endif
+		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
+		auto kernel = decode_linear<Dec, EPI, true>;
+		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 	} else {
-		hipLaunchKernelGGL((decode_linear_clipped<Dec, EPI>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.width,
-			g.height, g.pitch, g.status);
+		hipLaunchKernelGGL((decode_linear_clipped<typename PlainDecoder<Dec>::type, EPI>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n,
+			g.width, g.height, g.pitch, g.status);
 	}
 	return hipGetLastError();
 }
@@ -148,14 +159,17 @@ template <class Dec> hipError_t launch_linear(const Geometry &g) {
 }
 
 template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
-	const dim3 grid((unsigned)((a.n + 255u) / 256u)), block(256);
+	const uint32_t tiles = (uint32_t)((a.n + 255u) / 256u);
 	uint8_t *px = static_cast<uint8_t *>(a.pixels);
-	if (a.checked)
-		hipLaunchKernelGGL((decode_blocks<Dec, EPI, true>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+	if (a.checked) {
+		auto kernel = decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>;
+		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
-	else
-		hipLaunchKernelGGL((decode_blocks<Dec, EPI, false>), grid, block, 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+	} else {
+		auto kernel = decode_blocks<Dec, EPI, false>;
+		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
+	}
 	return hipGetLastError();
 }
 
@@ -184,7 +198,7 @@ template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
 	}
 	const uint32_t grid = a.table.wg_start[a.table.n_levels];
 	if (grid == 0) return hipSuccess;
-	hipLaunchKernelGGL((decode_levels<Dec, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status);
+	hipLaunchKernelGGL((decode_levels<typename PlainDecoder<Dec>::type, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status);
 	return hipGetLastError();
 }
 template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
@@ -308,7 +322,7 @@ int current_variant() {
 	if (c.variant < 0) {
 		const char *env = getenv("DETEXHIP_VARIANT");
 		c.variant = env ? atoi(env) : 0;
-		if (c.variant < 0 || c.variant > 6) c.variant = 0;
+		if (c.variant < 0 || c.variant > kMaxVariant) c.variant = 0;
 	}
 	return c.variant;
 }
@@ -373,7 +387,7 @@ extern "C" int detexhipSetDevice(int device) {
 
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
-extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= 6) ? variant : 0; }
+extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= kMaxVariant) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
 
 extern "C" const char *detexhipKernelName(uint32_t texture_format) {

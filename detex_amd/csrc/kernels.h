@@ -179,36 +179,39 @@ DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_
 }
 
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
-template <class Dec, int EPI, bool NT, bool XCD_CHUNKS = false>
+// A workgroup decodes tiles blockIdx.x, blockIdx.x + gridDim.x, ... of 256 consecutive blocks.  The host launches
+// one workgroup per tile, except for decoders with sizeable LDS tables (Dec::kPersistent: BC7), which get a grid
+// that just fills the chip so that the table copy at kernel entry is paid once per resident workgroup rather
+// than once per 256 blocks.  Per-lane LDS rows need no barrier between tiles: a lane only reads what it wrote.
+template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
 	prepare_tables<Dec>();
-	// XCD_CHUNKS (A/B, variant 6): workgroups are dealt round-robin to the 8 XCDs, so giving workgroup w the tile
-	// (w % 8) * (grid / 8) + w / 8 makes every XCD (and its L2) own one contiguous eighth of the image instead of
-	// every eighth 4 KiB row segment.  Measured no better than the plain order.
-	const uint32_t tile = XCD_CHUNKS && (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-	const uint32_t i = tile * 256u + threadIdx.x;
-	if constexpr (ROW == 8 && NT) {
-		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
-		const bool live = i < n_blocks;
-		uint32_t o[4 * ROW];
-		bool ok = true;
-		if (live) ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
-		store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
-		if (live) raise_status(!ok, status);
-		return;
-	}
-	if (i >= n_blocks) return;
-	uint32_t o[4 * ROW];
-	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
-	uint32_t by, bx;
-	split_index(i, width_in_blocks, by, bx);
-	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
+	const uint32_t n_tiles = (n_blocks + 255u) >> 8;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t i = tile * 256u + threadIdx.x;
+		if constexpr (ROW == 8 && NT) {
+			// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
+			const bool live = i < n_blocks;
+			uint32_t o[4 * ROW];
+			bool ok = true;
+			if (live) ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
+			if (live) raise_status(!ok, status);
+		} else {
+			if (i >= n_blocks) continue;
+			uint32_t o[4 * ROW];
+			const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+			uint32_t by, bx;
+			split_index(i, width_in_blocks, by, bx);
+			uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 #pragma unroll
-	for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
-	raise_status(!ok, status);
+			for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
+			raise_status(!ok, status);
+		}
+	}
 }
 
 // ---- linear layout, clipped / unaligned path (texture.c:116-120,132-136) ----------------------
@@ -285,59 +288,62 @@ __global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ bl
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;	// = 16-byte vectors per decoded block
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	const bool live = i < n_blocks;
-	if constexpr (ROW == 1) {
-		// 16 bytes per block: the wave's output is already one contiguous 1 KiB run per store instruction
-		if (!live) return;
-		uint32_t o[4];
-		const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
-		__builtin_nontemporal_store(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
-		if (ok_out) ok_out[i] = ok ? 1 : 0;
-		raise_status(!ok, status);
-	} else {
-		// A lane's block is ROW vectors = 16*ROW contiguous bytes, so a direct store instruction would write
-		// 16 bytes out of every 16*ROW: partial lines, measured 91 us against 43 us for the linear layout on
-		// BC1 8192^2.  The wave's blocks are contiguous in the output, so they go through LDS and are written
-		// back as ROW instructions of one contiguous 1 KiB run each.  LDS layout [vector k of the block][block],
-		// row stride GROUP + 16/ROW vectors: the writes (consecutive lanes, consecutive 16-byte slots) and the
-		// transposed reads (output vector e = block*ROW + k) are both bank-conflict free; a lane-major layout
-		// costs an 8-way conflict on every access for the 128-byte BC6H blocks.  64-bit pixels take two passes
-		// of 32 blocks so that 17 KiB per workgroup suffice for every pixel size.  Lanes past the end of the
-		// stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
-		constexpr int PASSES = ROW == 8 ? 2 : 1, GROUP = 64 / PASSES;		// blocks per pass
-		constexpr int STRIDE = GROUP + (16 % ROW == 0 ? 16 / ROW : 5);
-		__shared__ v4 stage[4][ROW * STRIDE];
-		v4 *slab = stage[threadIdx.x >> 6];
-		const uint32_t lane = threadIdx.x & 63u;
-		uint32_t o[4 * ROW];
-		bool ok = true;
-		if (live) ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
-		const uint32_t first = i - lane;						// the wave's first block
-		const uint32_t vectors = (first < n_blocks ? min(64u, n_blocks - first) : 0u) * ROW;
-		v4 *out = reinterpret_cast<v4 *>(pixels) + (uint64_t)first * ROW;
+	const uint32_t n_tiles = (n_blocks + 255u) >> 8;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {		// see decode_linear
+		const uint32_t i = tile * 256u + threadIdx.x;
+		const bool live = i < n_blocks;
+		if constexpr (ROW == 1) {
+			// 16 bytes per block: the wave's output is already one contiguous 1 KiB run per store instruction
+			if (!live) continue;
+			uint32_t o[4];
+			const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
+			__builtin_nontemporal_store(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
+			if (ok_out) ok_out[i] = ok ? 1 : 0;
+			raise_status(!ok, status);
+		} else {
+			// A lane's block is ROW vectors = 16*ROW contiguous bytes, so a direct store instruction would write
+			// 16 bytes out of every 16*ROW: partial lines, measured 91 us against 43 us for the linear layout on
+			// BC1 8192^2.  The wave's blocks are contiguous in the output, so they go through LDS and are written
+			// back as ROW instructions of one contiguous 1 KiB run each.  LDS layout [vector k of the block][block],
+			// row stride GROUP + 16/ROW vectors: the writes (consecutive lanes, consecutive 16-byte slots) and the
+			// transposed reads (output vector e = block*ROW + k) are both bank-conflict free; a lane-major layout
+			// costs an 8-way conflict on every access for the 128-byte BC6H blocks.  64-bit pixels take two passes
+			// of 32 blocks so that 17 KiB per workgroup suffice for every pixel size.  Lanes past the end of the
+			// stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
+			constexpr int PASSES = ROW == 8 ? 2 : 1, GROUP = 64 / PASSES;		// blocks per pass
+			constexpr int STRIDE = GROUP + (16 % ROW == 0 ? 16 / ROW : 5);
+			__shared__ v4 stage[4][ROW * STRIDE];
+			v4 *slab = stage[threadIdx.x >> 6];
+			const uint32_t lane = threadIdx.x & 63u;
+			uint32_t o[4 * ROW];
+			bool ok = true;
+			if (live) ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
+			const uint32_t first = i - lane;						// the wave's first block
+			const uint32_t vectors = (first < n_blocks ? min(64u, n_blocks - first) : 0u) * ROW;
+			v4 *out = reinterpret_cast<v4 *>(pixels) + (uint64_t)first * ROW;
 #pragma unroll
-		for (int p = 0; p < PASSES; p++) {
-			if (live && (PASSES == 1 || lane / GROUP == (uint32_t)p)) {
+			for (int p = 0; p < PASSES; p++) {
+				if (live && (PASSES == 1 || lane / GROUP == (uint32_t)p)) {
 #pragma unroll
-				for (int k = 0; k < ROW; k++) slab[k * STRIDE + lane % GROUP] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+					for (int k = 0; k < ROW; k++) slab[k * STRIDE + lane % GROUP] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+				}
+				// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+				for (int j = 0; j < GROUP * ROW / 64; j++) {
+					const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
+					const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
+					if (g < vectors) __builtin_nontemporal_store(slab[(e % ROW) * STRIDE + e / ROW], out + g);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
-			// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-			for (int j = 0; j < GROUP * ROW / 64; j++) {
-				const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
-				const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
-				if (g < vectors) __builtin_nontemporal_store(slab[(e % ROW) * STRIDE + e / ROW], out + g);
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
+			if (!live) continue;
+			if (ok_out) ok_out[i] = ok ? 1 : 0;
+			raise_status(!ok, status);
 		}
-		if (!live) return;
-		if (ok_out) ok_out[i] = ok ? 1 : 0;
-		raise_status(!ok, status);
 	}
 }
 

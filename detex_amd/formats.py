@@ -79,6 +79,7 @@ PIXEL_FORMAT_BGRA8 = 0x33C
 PIXEL_FORMAT_BGRX8 = 0x328
 PIXEL_FORMAT_RGB8 = 0x220
 PIXEL_FORMAT_FLOAT_BGRX16 = 0x2729
+PIXEL_FORMAT_NAMES = {**_PIXEL_NAMES, 0x33C: "BGRA8", 0x328: "BGRX8", 0x220: "RGB8", 0x2729: "FLOAT_BGRX16"}
 
 # epilogue kinds (detex_amd/csrc/kernels.h, oracle orc_convert_pixels): 0 none, 1 swap R/B (8-bit),
 # 2 pack RGB8, 3 swap R/B (16-bit)

@@ -38,24 +38,46 @@ def decode_shard(decode_fn, fmt, blocks, width, height, rank, world):
     return s, ok, pixels
 
 
-def gather_image(dist, torch, fmt, width, height, shard, local_pixels, local_ok=True, group=None):
-    """Optional whole-image gather: every rank ends up with the full row-major image and the AND
-    of the per-rank ok flags (the reference's bool result, texture.c:144).  Bands differ by at
-    most one block row, so the exchange is one all_gather of equal-size padded chunks (RCCL on the
-    GPU box: direct peer sends over xGMI; gloo in the CPU tests)."""
-    world = dist.get_world_size(group)
-    px = fmt.pixel_bytes
+def gather_layout(world, fmt, width, height):
+    """Equal-size chunk layout of the optional whole-image gather: rank r's band starts at
+    r*chunk in a world*chunk staging image, chunk = the largest band.  Bands differ by at most
+    one block row, so when height_in_blocks % world == 0 (every BASELINE config) the staging
+    image IS the final image and the gather is a single collective with no copy before or after."""
     sizes = [shard_of(r, world, fmt, width, height).out_bytes for r in range(world)]
     chunk = max(sizes) if sizes else 0
-    send = torch.zeros(chunk + 1, dtype=torch.uint8, device=local_pixels.device)
-    send[:shard.out_bytes] = local_pixels.reshape(-1)[:shard.out_bytes]
-    send[chunk] = 1 if local_ok else 0
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    image = torch.empty(width * height * px, dtype=torch.uint8, device=local_pixels.device)
-    ok = True
-    for r in range(world):
-        s = shard_of(r, world, fmt, width, height)
-        image[s.out_offset:s.out_offset + s.out_bytes] = recv[r][:s.out_bytes]
-        ok = ok and bool(recv[r][chunk].item())
-    return ok, image
+    exact = all(shard_of(r, world, fmt, width, height).out_offset == r * chunk for r in range(world)) and \
+        sum(sizes) == world * chunk
+    return chunk, sizes, exact
+
+
+def gather_image(dist, torch, fmt, width, height, shard, local_pixels, local_ok=True, group=None, image=None):
+    """Optional whole-image gather: every rank ends up with the full row-major image and the AND
+    of the per-rank ok flags (the reference's bool result, texture.c:144).
+
+    ONE all_gather_into_tensor (RCCL on the GPU box: direct peer transfers over xGMI; gloo in the
+    CPU tests) of equal chunks, received straight into the final image when the bands are equal
+    (gather_layout(...).exact); otherwise the short bands are padded at the tail and the image is
+    compacted once.  The ok flags travel as one extra all_reduce(MIN) of a single byte-sized
+    tensor.  `image` may be a preallocated world*chunk (exact: width*height*px) uint8 tensor."""
+    world = dist.get_world_size(group)
+    px = fmt.pixel_bytes
+    chunk, sizes, exact = gather_layout(world, fmt, width, height)
+    dev = local_pixels.device
+    flat = local_pixels.reshape(-1)
+    if flat.numel() == chunk:
+        send = flat
+    else:                                   # a band one block row short: pad the tail
+        send = torch.zeros(chunk, dtype=torch.uint8, device=dev)
+        send[:shard.out_bytes] = flat[:shard.out_bytes]
+    if image is None or image.numel() != world * chunk:
+        image = torch.empty(world * chunk, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(image, send, group=group)
+    flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if not exact:
+        out = torch.empty(width * height * px, dtype=torch.uint8, device=dev)
+        for r in range(world):
+            s = shard_of(r, world, fmt, width, height)
+            out[s.out_offset:s.out_offset + s.out_bytes] = image[r * chunk:r * chunk + s.out_bytes]
+        image = out
+    return bool(flag.item()), image

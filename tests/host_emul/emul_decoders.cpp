@@ -45,8 +45,7 @@ extern "C" int emul_decode_blocks(int fmt, const uint8_t *in, long n, uint32_t m
 	case 110: run<DecBPTCFloatT<true, true>>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 10: run<DecBPTCSignedFloat>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 11: run<DecBPTC>(in, n, mode_mask, flags, checked, out, ok); break;
-	case 111: run<DecBPTCRegisterSelect>(in, n, mode_mask, flags, checked, out, ok); break;
-	case 112: run<DecBPTCRegisterFields>(in, n, mode_mask, flags, checked, out, ok); break;
+	case 111: run<DecBPTCPlain>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 12: run<DecETC1>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 13: run<DecETC2>(in, n, mode_mask, flags, checked, out, ok); break;
 	case 14: run<DecETC2Punchthrough>(in, n, mode_mask, flags, checked, out, ok); break;

@@ -196,3 +196,28 @@ def stream_m(fmt, base):
         keep = np.where((i % 14) < 2, 0xFC, 0xE0).astype(np.uint8)
         b[:, 0] = (b[:, 0] & keep) | codes
     return b.reshape(-1)
+
+
+def stream_c(fmt, wb, hb):
+    """Stream C: the reference's bundled 64x64 fixture of this format (16x16 blocks,
+    tests/golden/test-texture-<FMT>.ktx; file list validate.c:31-57) tiled over wb x hb blocks --
+    coherent, encoder-made content.  None for the two formats the reference ships no fixture for."""
+    import os
+    from detex_amd.ktx import read_ktx
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-texture-%s.ktx" % fmt.name)
+    if not os.path.exists(path):
+        return None
+    k = read_ktx(path)
+    fw, fh = k["width_in_blocks"], k["height_in_blocks"]
+    tile = k["data"].reshape(fh, fw, fmt.block_bytes)
+    reps = ((hb + fh - 1) // fh, (wb + fw - 1) // fw, 1)
+    return np.ascontiguousarray(np.tile(tile, reps)[:hb, :wb]).reshape(-1)
+
+
+def make_stream(kind, fmt, wb, hb, seed=None):
+    """'U', 'M' or 'C' stream of wb x hb blocks (None if the kind does not exist for fmt)."""
+    import oracle_lib as ol
+    if kind == "C":
+        return stream_c(fmt, wb, hb)
+    data = ol.stream_u(fmt, wb * hb, seed=seed)
+    return stream_m(fmt, data) if kind == "M" else data
