@@ -39,17 +39,19 @@ constexpr Bc7ModeDesc kBc7Modes[8] = {
 	{ 1, 0, 2, 1, 5, 6, 0, 0, 2, 3 }, { 1, 0, 2, 0, 7, 8, 0, 0, 2, 2 }, { 1, 0, 0, 0, 7, 7, 1, 0, 4, 0 }, { 2, 6, 0, 0, 5, 5, 1, 0, 2, 0 } };
 
 // ---- partition / anchor table -------------------------------------------------------------------------
-// One entry per (partition table, index width) pair a block can name, 6 dwords:
-//   m_lo1, m_lo2   high masks of the zero bits to insert into the first index window (texels 0-7) for the
-//                  anchors of subsets 1 and 2 that lie there, ascending; 0 = none (texel 0's is in the record)
-//   m_hi1, m_hi2   the same for the second window (texels 8-15)
-//   half           bits the first window consumes from the stream = 8*ib - (anchors among texels 0-7)
-//   pword          2-bit subset number per texel
+// One entry per (partition table, index width) pair a block can name, 2 dwords:
+//   pword   2-bit subset number per texel
+//   route   five 5-bit fields: positions of the zero bits to insert into the first index window (texels 0-7) for the
+//           anchors of subsets 1 and 2 that lie there, ascending (lo1, lo2), the same for the second window (texels
+//           8-15: hi1, hi2) -- 31 = none: every window of a partitioned mode is at most 24 bits wide, so an insertion
+//           at bit 31 touches nothing that is read (one-subset modes shift a zero word instead of all-ones: record
+//           field ins_ones) -- and `half`, the bits the first window consumes from the stream
+//           = 8*ib - (anchors among texels 0-7).  Texel 0's own anchor bit is in the record.
 // Sections: [0,64) two subsets ib 2 (modes 3, 7) . [64,128) two subsets ib 3 (mode 1) . [128,192) three
 // subsets ib 2 (mode 2) . [192,208) three subsets ib 3 (mode 0, 4-bit partition number) . 208/209/210 one
 // subset with ib 2/3/4 (modes 4, 5, 6: only `half` matters).
 constexpr int kBc7PartEntries = 211;
-struct Bc7PartEntry { uint32_t m_lo1, m_lo2, m_hi1, m_hi2, half, pword; };
+struct Bc7PartEntry { uint32_t pword, route; };
 struct Bc7PartTable { Bc7PartEntry e[kBc7PartEntries]; };
 constexpr Bc7PartEntry bc7_part_entry(int subsets, uint32_t ib, uint32_t part) {
 	Bc7PartEntry r = {};
@@ -60,15 +62,13 @@ constexpr Bc7PartEntry bc7_part_entry(int subsets, uint32_t ib, uint32_t part) {
 		r.pword = kPartition2BitCx[64u + part];
 		if (a[0] > a[1]) { const uint32_t t = a[0]; a[0] = a[1]; a[1] = t; }
 	}
-	uint32_t nlo = 1u, lo[2] = { 0u, 0u }, hi[2] = { 0u, 0u }, klo = 0u, khi = 0u;
+	uint32_t nlo = 1u, lo[2] = { 31u, 31u }, hi[2] = { 31u, 31u }, klo = 0u, khi = 0u;
 	for (int k = 0; k < 2; k++) {
 		if (a[k] > 15u) continue;
 		const uint32_t pos = (a[k] & 7u) * ib + ib - 1u;	// where the anchor's absent MSB belongs in its window
-		const uint32_t himask = 0xFFFFFFFFu << pos;
-		if (a[k] < 8u) { lo[klo++] = himask; nlo++; } else hi[khi++] = himask;
+		if (a[k] < 8u) { lo[klo++] = pos; nlo++; } else hi[khi++] = pos;
 	}
-	r.m_lo1 = lo[0]; r.m_lo2 = lo[1]; r.m_hi1 = hi[0]; r.m_hi2 = hi[1];
-	r.half = 8u * ib - nlo;
+	r.route = lo[0] | (lo[1] << 5) | (hi[0] << 10) | (hi[1] << 15) | ((8u * ib - nlo) << 20);
 	return r;
 }
 constexpr Bc7PartTable bc7_part_table() {
@@ -99,7 +99,7 @@ struct alignas(16) Bc7Rec {
 	uint32_t wmul_c, wadd_c, himask0_c, two;		// weight = byte 2 of index * mul + add; texel 0's anchor bit; has a second stream
 	uint32_t row_a2, pos_a2, iba, imask_a;			// alpha index stream (modes 4, 5)
 	uint32_t wmul_a, wadd_a, himask0_a, half_a;
-	uint32_t sel_ba, mode, pad0, pad1;			// v_perm selector building (colour weight, alpha weight)
+	uint32_t sel_ba, mode, ins_ones, pad1;			// v_perm selector building (colour weight, alpha weight); ~0 if the mode has partitions
 };
 static_assert(sizeof(Bc7Rec) == 208, "record is fetched with 16-byte LDS reads; 52-dword stride keeps records on disjoint banks");
 constexpr int kBc7Recs = 9;
@@ -156,6 +156,7 @@ constexpr Bc7Rec bc7_rec(uint32_t mode, bool isel) {
 	// (colour weight, alpha weight) in 16-bit lanes from byte 2 of the two mads; blocks without a second stream
 	// use the colour weight twice
 	L.sel_ba = two ? 0x0C060C02u : 0x0C020C02u;
+	L.ins_ones = m.ns == 1u ? 0u : 0xFFFFFFFFu;
 	return L;
 }
 struct Bc7RecTable { Bc7Rec r[kBc7Recs]; };
@@ -182,9 +183,17 @@ struct Bc7Lds {
 	Bc7Rec rec[kBc7Recs];
 	uint32_t gather[4];
 	Bc7PartEntry part[kBc7PartEntries];
-	uint32_t bits[6][256];			// per-lane block dwords; rows 4, 5 stay zero (bits beyond 127)
+	// per-lane block dwords, LAST member: fields that start near the end of the block also read "rows" 4 and 5,
+	// i.e. up to 2 KiB past this array -- LDS reads beyond the allocation return 0 rather than faulting, and whatever
+	// they return stands for bits beyond 127, which no field or index ever consumes
+	uint32_t bits[4][256];
+#if defined(DETEXHIP_EXP_LDS_PAD)		// measurement build: lower the occupancy
+	uint32_t pad[DETEXHIP_EXP_LDS_PAD / 4];
+#endif
 };
-static_assert(sizeof(Bc7Lds) <= 27306, "six workgroups per CU");
+#if !defined(DETEXHIP_EXP_LDS_PAD)
+static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU");
+#endif
 DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
 DH void bc7_prepare() {
 	Bc7Lds &s = bc7_lds();
@@ -202,7 +211,6 @@ DH void bc7_prepare() {
 		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
 	}
 	if (k < 4u) s.gather[k] = kBc7Gather[k];
-	s.bits[4][k] = 0u; s.bits[5][k] = 0u;
 	__syncthreads();
 }
 #endif
@@ -253,7 +261,7 @@ struct Bc7Lane {
 #else
 	uint32_t bits[6];
 	uint4 subset[3];
-	DH Bc7Lane() { for (int k = 0; k < 6; k++) bits[k] = 0u; }
+	DH Bc7Lane() { for (int k = 0; k < 6; k++) bits[k] = 0xA5A5A5A5u; }	// rows 4, 5: arbitrary (device: whatever follows in LDS)
 	DH void put_bits(uint4 blk) { bits[0] = blk.x; bits[1] = blk.y; bits[2] = blk.z; bits[3] = blk.w; }
 	DH uint32_t field(uint32_t row, uint32_t pos) const {
 		const uint32_t k = row / kBc7RowBytes;
@@ -343,12 +351,14 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	// part of w at and above the insertion point), after which texel k of a window sits at bit k*ib.
 	uint32_t c0, c1;
 	lane.field64(L.row_c, L.pos_c, c0, c1);
-	uint32_t cw = c0, cw_hi = __builtin_amdgcn_alignbit(c1, c0, pe.half);
+	const uint32_t route = pe.route;			// shifts use the low 5 bits of their amount
+	uint32_t cw = c0, cw_hi = __builtin_amdgcn_alignbit(c1, c0, route >> 20);
 	cw += cw & L.himask0_c;
-	cw += cw & pe.m_lo1;
-	cw += cw & pe.m_lo2;
-	cw_hi += cw_hi & pe.m_hi1;
-	cw_hi += cw_hi & pe.m_hi2;
+	const uint32_t ones = L.ins_ones;
+	cw += cw & (ones << (route & 31u));
+	cw += cw & (ones << ((route >> 5) & 31u));
+	cw_hi += cw_hi & (ones << ((route >> 10) & 31u));
+	cw_hi += cw_hi & (ones << ((route >> 15) & 31u));
 	const uint32_t ibc = L.ibc, imask_c = L.imask_c, wmul_c = L.wmul_c, wadd_c = L.wadd_c;
 
 	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
@@ -392,7 +402,18 @@ DH uint32_t bc7_record_index(uint32_t first_dword) {
 // throughput path -- clipped geometry, the checked per-block batch -- instantiate the plain form to bound code size)
 template <bool UNIFORM> struct DecBPTCT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
+#if defined(DETEXHIP_EXP_BC7_WAVES)
+	static constexpr int kWavesPerSimd = DETEXHIP_EXP_BC7_WAVES;
+#else
+	// <= 72 VGPRs: seven waves per SIMD (eight would spill; measured 59 vs 65 us on stream U).  LDS (<= 20 KiB per
+	// workgroup) would admit eight workgroups per CU.
+	static constexpr int kWavesPerSimd = 7;
+#endif
+#if defined(DETEXHIP_EXP_BC7_NONPERSISTENT)	// measurement build
+	static constexpr bool kPersistent = false;
+#else
 	static constexpr bool kPersistent = true;	// sizeable LDS tables: workgroups loop over tiles (kernels.h)
+#endif
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
 #endif
@@ -420,7 +441,11 @@ template <bool UNIFORM> struct DecBPTCT {
 		return bc7_decode_with<-1, CHECKED>(blk, r, mode_mask, flags, d);
 	}
 };
+#if defined(DETEXHIP_EXP_BC7_PLAIN)		// measurement build: no wave-uniform specialisations
+using DecBPTC = DecBPTCT<false>;
+#else
 using DecBPTC = DecBPTCT<true>;
+#endif
 using DecBPTCPlain = DecBPTCT<false>;
 
 }  // namespace detexhip

@@ -19,9 +19,19 @@
 // Invalid blocks are zero-filled and raise *status (texture.c:125-128 semantics): one relaxed
 // agent-scope load + (only while it still reads 0) one store per wave, never an atomic RMW.
 #pragma once
+#include <type_traits>
 #include "dev_common.h"
 
 namespace detexhip {
+
+// decoders with sizeable LDS tables (Dec::kPersistent) run on a grid that just fills the chip, each workgroup looping
+// over tiles of 256 blocks, so the table copy at kernel entry is paid once per resident workgroup
+template <class Dec, class = void> struct PersistentTiles { static constexpr bool value = false; };
+template <class Dec> struct PersistentTiles<Dec, std::enable_if_t<Dec::kPersistent>> { static constexpr bool value = true; };
+
+// waves per SIMD the register allocation must leave room for (Dec::kWavesPerSimd; default: no constraint)
+template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
+template <class Dec> struct WavesPerSimd<Dec, std::enable_if_t<(Dec::kWavesPerSimd > 0)>> { static constexpr int value = Dec::kWavesPerSimd; };
 
 template <int BYTES> struct BlockWord;
 template <> struct BlockWord<8> { using type = uint2; };
@@ -161,15 +171,31 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 	}
 }
 
+// the block of lane i as ONE 8/16-byte load (left to itself the compiler loads the first dword, tests the
+// decoders' early-outs on it and only then fetches the rest: two dependent HBM round trips per block)
+template <class Dec> DH typename BlockWord<Dec::kBlockBytes>::type load_block(const void *blocks, uint32_t i) {
+	using Word = typename BlockWord<Dec::kBlockBytes>::type;
+	Word blk = reinterpret_cast<const Word *>(blocks)[i];
+#if defined(__HIPCC__)
+	if constexpr (Dec::kBlockBytes == 16) asm volatile("" : "+v"(blk.x), "+v"(blk.y), "+v"(blk.z), "+v"(blk.w));
+	else asm volatile("" : "+v"(blk.x), "+v"(blk.y));
+#endif
+	return blk;
+}
+
 // decode + zero-fill on failure + epilogue; returns ok
 template <class Dec, int EPI, bool CHECKED>
-DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
+DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint32_t mode_mask, uint32_t flags,
 		uint32_t (&o)[4 * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords]) {
 	constexpr int P = Dec::kPixelBytes;
-	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	const Word blk = reinterpret_cast<const Word *>(blocks)[i];
 	uint32_t d[4 * P];
+#if defined(DETEXHIP_EXP_NOCOMPUTE)	// measurement build: memory traffic without the decode
+	bool ok = true;
+#pragma unroll
+	for (int k = 0; k < 4 * P; k++) d[k] = (k & 1) ? blk.y : blk.x;
+#else
 	const bool ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
+#endif
 	if (!ok) {
 #pragma unroll
 		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
@@ -177,39 +203,67 @@ DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_
 	Epilogue<EPI, P>::apply(d, o);
 	return ok;
 }
+template <class Dec, int EPI, bool CHECKED>
+DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
+		uint32_t (&o)[4 * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords]) {
+	return decode_word<Dec, EPI, CHECKED>(load_block<Dec>(blocks, i), mode_mask, flags, o);
+}
+#if defined(DETEXHIP_EXP_NOSTORE)	// measurement build: the decode without its stores (the condition is practically never true)
+#define DETEXHIP_STORE_IF(o) if ((o)[0] == 0x9E3779B9u && (o)[1] == 0x7F4A7C15u)
+#else
+#define DETEXHIP_STORE_IF(o)
+#endif
 
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
-// A workgroup decodes tiles blockIdx.x, blockIdx.x + gridDim.x, ... of 256 consecutive blocks.  The host launches
-// one workgroup per tile, except for decoders with sizeable LDS tables (Dec::kPersistent: BC7), which get a grid
-// that just fills the chip so that the table copy at kernel entry is paid once per resident workgroup rather
-// than once per 256 blocks.  Per-lane LDS rows need no barrier between tiles: a lane only reads what it wrote.
+// One workgroup per tile of 256 consecutive blocks -- except for decoders with sizeable LDS tables (PersistentTiles:
+// BC7), whose workgroups decode tiles blockIdx.x, blockIdx.x + gridDim.x, ... on a grid that just fills the chip.
+// Per-lane LDS rows need no barrier between tiles: a lane only reads what it wrote.
 template <class Dec, int EPI, bool NT>
-__global__ __launch_bounds__(256) void decode_linear(const void *__restrict__ blocks,
+__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	using Word = typename BlockWord<Dec::kBlockBytes>::type;
+	// the first block is requested before the table copy, so its HBM round trip overlaps the copy and the barrier
+	const uint32_t first = blockIdx.x * 256u + threadIdx.x;
+	Word blk = {};
+	if (first < n_blocks) blk = load_block<Dec>(blocks, first);
 	prepare_tables<Dec>();
-	const uint32_t n_tiles = (n_blocks + 255u) >> 8;
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	auto decode_tile = [&](uint32_t tile, const Word &cur) {
 		const uint32_t i = tile * 256u + threadIdx.x;
 		if constexpr (ROW == 8 && NT) {
 			// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
 			const bool live = i < n_blocks;
 			uint32_t o[4 * ROW];
 			bool ok = true;
-			if (live) ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+			if (live) ok = decode_word<Dec, EPI, false>(cur, 0xFFFFFFFFu, 0u, o);
+			DETEXHIP_STORE_IF(o)
 			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
 			if (live) raise_status(!ok, status);
 		} else {
-			if (i >= n_blocks) continue;
+			if (i >= n_blocks) return;
 			uint32_t o[4 * ROW];
-			const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+			const bool ok = decode_word<Dec, EPI, false>(cur, 0xFFFFFFFFu, 0u, o);
 			uint32_t by, bx;
 			split_index(i, width_in_blocks, by, bx);
 			uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
+			DETEXHIP_STORE_IF(o) {
 #pragma unroll
-			for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
+				for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
+			}
 			raise_status(!ok, status);
+		}
+	};
+	if constexpr (!PersistentTiles<Dec>::value) {
+		decode_tile(blockIdx.x, blk);			// one workgroup per tile
+	} else {
+		// software pipeline over the workgroup's tiles: the next tile's block is requested before this one is decoded
+		const uint32_t n_tiles = (n_blocks + 255u) >> 8;
+		for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			const Word cur = blk;
+			const uint32_t i_next = (tile + gridDim.x) * 256u + threadIdx.x;
+			if (tile + gridDim.x < n_tiles && i_next < n_blocks) blk = load_block<Dec>(blocks, i_next);
+			decode_tile(tile, cur);
 		}
 	}
 }
@@ -282,14 +336,14 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 // ---- block-major output (detexDecompressTextureTiled, texture.c:77-98) and the batched form of
 // the per-block API (mode_mask / flags honoured, per-block ok byte) ----------------------------
 template <class Dec, int EPI, bool CHECKED>
-__global__ __launch_bounds__(256) void decode_blocks(const void *__restrict__ blocks,
+__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
 		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
 	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;	// = 16-byte vectors per decoded block
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
-	const uint32_t n_tiles = (n_blocks + 255u) >> 8;
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {		// see decode_linear
+	const uint32_t n_tiles = PersistentTiles<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t i = tile * 256u + threadIdx.x;
 		const bool live = i < n_blocks;
 		if constexpr (ROW == 1) {

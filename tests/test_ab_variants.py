@@ -14,8 +14,15 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif("_ab" not in os.path.basename(
                                                   reason="needs DETEXHIP_LIB=<A/B build of libdetexhip>")]
 
 
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
 def _dev(torch, a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda()
 
 
 def _first_diff(got, want, unit):

@@ -1,0 +1,20 @@
+#!/bin/bash
+# measurement builds of libdetexhip (never shipped): bash tools/build_exp_libs.sh nostore nocompute pad8192 ...
+set -e
+cd "$(dirname "$0")/.."
+for v in "$@"; do
+  case $v in
+    nostore) D=-DDETEXHIP_EXP_NOSTORE ;;
+    nocompute) D=-DDETEXHIP_EXP_NOCOMPUTE ;;
+    pad*) D=-DDETEXHIP_EXP_LDS_PAD=${v#pad} ;;
+    waves*) D=-DDETEXHIP_EXP_BC7_WAVES=${v#waves} ;;
+    nonpersistent) D=-DDETEXHIP_EXP_BC7_NONPERSISTENT ;;
+    plain) D=-DDETEXHIP_EXP_BC7_PLAIN ;;
+    plain_nonpersistent) D="-DDETEXHIP_EXP_BC7_PLAIN -DDETEXHIP_EXP_BC7_NONPERSISTENT" ;;
+    *) D="$EXP_DEFS" ;;
+  esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $D -Wall -Wno-unused-function \
+    -o detex_amd/lib/libdetexhip_exp_$v.so detex_amd/csrc/detexhip.hip detex_amd/csrc/ktx_loader.cpp &
+done
+wait
+ls -la detex_amd/lib
