@@ -141,3 +141,60 @@ def mode_histogram_device(fmt, blocks, n_blocks, hist=None, stream=None):
     _check(lib.detexhipModeHistogramDevice(fmt.texture_format, blocks.data_ptr(), n_blocks, hist.data_ptr(), _stream_handle(stream)),
            "detexhipModeHistogramDevice")
     return hist
+
+
+class Shard(ctypes.Structure):
+    """detexhipShard (include/detexhip.h)"""
+    _fields_ = [("device", ctypes.c_int), ("d_blocks", ctypes.c_void_p), ("d_pixels", ctypes.c_void_p),
+                ("row0", ctypes.c_int), ("row1", ctypes.c_int), ("decode_ms", ctypes.c_float), ("invalid_blocks", ctypes.c_int)]
+
+
+def shard_rows(height_in_blocks, n_shards, shard):
+    lib = load()
+    r0, r1 = ctypes.c_int(), ctypes.c_int()
+    _check(lib.detexhipShardRows(height_in_blocks, n_shards, shard, ctypes.byref(r0), ctypes.byref(r1)), "detexhipShardRows")
+    return r0.value, r1.value
+
+
+def decompress_linear_multi_device(fmt, width, height, devices, host_blocks=None, device_blocks=None, pixel_format=None,
+                                   gather_device=-1):
+    """detexhipDecompressTextureLinearMultiDevice: one texture, len(devices) shards of block rows, one calling
+    thread.  host_blocks: numpy uint8 of the whole stream (uploaded by the call) or device_blocks: one torch uint8
+    tensor per shard already on its device.  Returns dict(ok, bands=[torch tensors], gathered, shards, decode_wall_ms,
+    gather_wall_ms)."""
+    import numpy as np
+    import torch
+    lib = load()
+    lib.detexhipDecompressTextureLinearMultiDevice.argtypes = [
+        ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32,
+        ctypes.POINTER(Shard), ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    pf = F.native_pixel_format(fmt) if pixel_format is None else pixel_format
+    px = 1 + ((pf & 0xF00) >> 8)
+    wb, hb = (width + 3) // 4, (height + 3) // 4
+    n = len(devices)
+    shards = (Shard * n)()
+    bands = []
+    for g, dev in enumerate(devices):
+        r0, r1 = shard_rows(hb, n, g)
+        rows = max(0, min(r1 * 4, height) - r0 * 4)
+        band = torch.empty(max(rows * width * px, 16), dtype=torch.uint8, device="cuda:%d" % dev)
+        bands.append(band)
+        shards[g].device = dev
+        shards[g].d_blocks = None if device_blocks is None else device_blocks[g].data_ptr()
+        shards[g].d_pixels = band.data_ptr()
+    gathered = None
+    if gather_device >= 0:
+        gathered = torch.empty(width * height * px, dtype=torch.uint8, device="cuda:%d" % gather_device)
+    hb_ptr = None
+    if host_blocks is not None:
+        host_blocks = np.ascontiguousarray(host_blocks)
+        hb_ptr = host_blocks.ctypes.data_as(ctypes.c_void_p)
+    t_dec, t_gat = ctypes.c_float(), ctypes.c_float()
+    torch.cuda.synchronize()
+    _check(lib.detexhipDecompressTextureLinearMultiDevice(
+        fmt.texture_format, hb_ptr, width, height, wb, hb, 0, pf, shards, n, gather_device,
+        None if gathered is None else gathered.data_ptr(), ctypes.byref(t_dec), ctypes.byref(t_gat)),
+        "detexhipDecompressTextureLinearMultiDevice")
+    return {"ok": all(s.invalid_blocks == 0 for s in shards), "bands": bands, "gathered": gathered,
+            "shards": [(s.row0, s.row1, s.decode_ms, s.invalid_blocks) for s in shards],
+            "decode_wall_ms": t_dec.value, "gather_wall_ms": t_gat.value}

@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #define DETEXHIP_BUILDING_LIBRARY 1
@@ -109,7 +111,8 @@ template <class K> uint32_t resident_workgroups(K kernel) {
 // over tiles.  Measured on BC7 8192^2 (stream U / C, 7 workgroups per CU resident, same box): exactly the resident
 // count 59.7 / 52.9 us, a grid balanced to equal tile counts 62.6 / 55.8, 1.5x 60.1 / 52.0, 2x 58.8 / 50.7, 3x 58.7 / 51.1,
 // 5x 58.5 / 51.1, 9x (one tile each, the table copy paid per tile) 62.0 / 53.5: a second round lets the dispatcher even
-// out the CUs, more rounds only add table copies.
+// out the CUs, more rounds only add table copies.  Decoders without sizeable tables are 1-20 % SLOWER on a persistent
+// grid than with one workgroup per tile (measured for all of them), so only BC7 uses one.
 template <class Dec, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
 	if constexpr (PersistentTiles<Dec>::value) {
 		const uint32_t grid = 2u * resident_workgroups(kernel);
@@ -282,7 +285,8 @@ int epilogue_for(uint32_t texture_format, uint32_t pixel_format) {
 bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) { return epilogue_for(texture_format, pixel_format) >= 0; }
 
 // ------------------------------------------------------------------------------------------------
-// per-thread device context: stream + grow-only staging buffers for the host-pointer tier
+// per-thread device context of the host-pointer tier: a stream and grow-only device staging buffers that
+// detexhipReleaseThreadResources() hands back
 // ------------------------------------------------------------------------------------------------
 struct ThreadContext {
 	bool ready = false;
@@ -291,14 +295,39 @@ struct ThreadContext {
 	hipStream_t stream = nullptr;
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
-	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls
-	~ThreadContext() {
+	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls / histogram bins
+	void release() {
 		if (!ready) return;
+		int prev = -1;
+		(void)hipGetDevice(&prev);
+		(void)hipSetDevice(device);
+		(void)hipStreamSynchronize(stream);
 		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
 		(void)hipStreamDestroy(stream);
+		d_in = d_out = nullptr; d_status = nullptr; in_cap = out_cap = 0;
+		stream = nullptr;
+		ready = false;
+		if (prev >= 0) (void)hipSetDevice(prev);
 	}
+	~ThreadContext() { release(); }
 };
 thread_local ThreadContext t_ctx;
+
+// The host tier always runs on the context's device, whatever device the calling thread has made current since
+// (e.g. torch.cuda.set_device): entry points hold one of these for their duration and the caller's device is
+// restored on return.
+struct DeviceScope {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceScope(int device) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != device) {
+			hipError_t e = hipSetDevice(device);
+			if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); ok = false; }
+		}
+	}
+	~DeviceScope() { int now = -1; if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev); }
+};
 
 bool context_ready() {
 	ThreadContext &c = t_ctx;
@@ -314,7 +343,8 @@ bool context_ready() {
 		const char *env = getenv("DETEXHIP_DEVICE");
 		c.device = env ? atoi(env) : 0;
 	}
-	HIP_TRY(hipSetDevice(c.device), "hipSetDevice");
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
 	HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
 	HIP_TRY(hipMalloc(&c.d_status, 64), "hipMalloc(status)");
 	c.ready = true;
@@ -347,6 +377,8 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 		uint8_t *pixel_buffer, uint32_t pixel_format) {
 	if (!context_ready()) return -1;
 	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return -1;
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
 	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
 	if (!reserve(&c.d_in, &c.in_cap, 4096) || !reserve(&c.d_out, &c.out_cap, 4096)) return -1;
@@ -379,17 +411,23 @@ extern "C" int detexhipGetDeviceCount(void) {
 }
 
 extern "C" int detexhipSetDevice(int device) {
-	hipError_t e = hipSetDevice(device);
-	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); return 1; }
-	if (t_ctx.ready && t_ctx.device != device) {
-		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d) after this thread already used device %d", device, t_ctx.device);
+	if (t_ctx.ready && t_ctx.device != device) {	// checked BEFORE touching the current device
+		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d) after this thread already used device %d "
+			"(detexhipReleaseThreadResources() first)", device, t_ctx.device);
+		return 1;
+	}
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d): no such device (%d present)", device, count);
 		return 1;
 	}
 	t_ctx.device = device;
 	return 0;
 }
 
-extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.1 (gfx950; detex v0.1.2 block-decode ABI)"; }
+extern "C" void detexhipReleaseThreadResources(void) { t_ctx.release(); }
+
+extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.2 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
 extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= kMaxVariant) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
@@ -441,7 +479,10 @@ extern "C" int detexhipModeHistogramDevice(uint32_t texture_format, const void *
 		void *stream) {
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("detexhipModeHistogramDevice: 0x%08X is not a block-compressed format of this library", texture_format); return 1; }
-	if (n_blocks > 0xFFFFFF00ull || !d_hist) { detexSetErrorMessage("detexhipModeHistogramDevice: bad arguments"); return 1; }
+	if (n_blocks > 0xFFFFFF00ull || !d_hist || reinterpret_cast<uintptr_t>(d_blocks) % detexGetCompressedBlockSize(texture_format) != 0) {
+		detexSetErrorMessage("detexhipModeHistogramDevice: bad arguments (d_hist NULL, d_blocks not block-aligned, or too many blocks)");
+		return 1;
+	}
 	hipError_t e = f->histogram(d_blocks, n_blocks, d_hist, static_cast<hipStream_t>(stream));
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -464,6 +505,10 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: bad geometry %dx%d (%dx%d blocks, pitch %zu)", width, height, width_in_blocks, height_in_blocks, pitch_bytes);
 		return 1;
 	}
+	if (reinterpret_cast<uintptr_t>(d_blocks) % detexGetCompressedBlockSize(texture_format) != 0) {	// blocks are fetched with one 8/16-byte load each
+		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: d_blocks must be %d-byte aligned", (int)detexGetCompressedBlockSize(texture_format));
+		return 1;
+	}
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
 		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epilogue_for(texture_format, pixel_format) };
 	hipError_t e = f->linear(g);
@@ -476,6 +521,11 @@ static int blocks_device(const char *who, uint32_t texture_format, const void *d
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
 	if (n_blocks > 0xFFFFFF00ull) { detexSetErrorMessage("%s: too many blocks", who); return 1; }
+	if (reinterpret_cast<uintptr_t>(d_blocks) % detexGetCompressedBlockSize(texture_format) != 0 || reinterpret_cast<uintptr_t>(d_pixels) % 16u != 0) {
+		detexSetErrorMessage("%s: d_blocks must be %d-byte aligned and d_pixels 16-byte aligned (block-major output is written with 16-byte vector stores)", who,
+			(int)detexGetCompressedBlockSize(texture_format));
+		return 1;
+	}
 	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, flags, d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi };
 	hipError_t e = f->blocks(a);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
@@ -498,6 +548,140 @@ extern "C" int detexhipDecompressBlocksDevice(uint32_t texture_format, const voi
 		uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream) {
 	return blocks_device("detexhipDecompressBlocksDevice", texture_format, d_blocks, n_blocks, mode_mask, flags, d_pixels, d_ok,
 		nullptr, stream, true, kEpiNone);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-device entry: one texture, N shards of block rows, one calling thread
+// ------------------------------------------------------------------------------------------------
+extern "C" int detexhipShardRows(int height_in_blocks, int n_shards, int shard, int *row0, int *row1) {
+	if (n_shards <= 0 || shard < 0 || shard >= n_shards || height_in_blocks < 0 || !row0 || !row1) {
+		detexSetErrorMessage("detexhipShardRows: bad arguments");
+		return 1;
+	}
+	*row0 = (int)((int64_t)shard * height_in_blocks / n_shards);
+	*row1 = (int)((int64_t)(shard + 1) * height_in_blocks / n_shards);
+	return 0;
+}
+
+namespace {
+struct ShardSlot {		// per shard index, process-wide, created on first use (a shard keeps its device between calls)
+	int device = -1;
+	hipStream_t stream = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	uint32_t *d_status = nullptr;
+	void *d_upload = nullptr;	// blocks uploaded from host_blocks for this call
+};
+std::mutex g_multi_mutex;
+ShardSlot g_shard_slots[64];
+
+hipError_t prepare_slot(ShardSlot &sl, int device) {
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return e;
+	if (sl.device == device && sl.stream) return hipSuccess;
+	if (sl.stream) {		// the shard moved to another device: drop what belonged to the old one
+		(void)hipSetDevice(sl.device);
+		(void)hipStreamDestroy(sl.stream); (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); (void)hipEventDestroy(sl.e2);
+		(void)hipFree(sl.d_status);
+		sl = ShardSlot{};
+		if ((e = hipSetDevice(device)) != hipSuccess) return e;
+	}
+	if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+	if ((e = hipEventCreate(&sl.e0)) != hipSuccess || (e = hipEventCreate(&sl.e1)) != hipSuccess || (e = hipEventCreate(&sl.e2)) != hipSuccess) return e;
+	if ((e = hipMalloc(&sl.d_status, 64)) != hipSuccess) return e;
+	sl.device = device;
+	return hipSuccess;
+}
+}  // namespace
+
+extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_format, const void *host_blocks, int width, int height,
+		int width_in_blocks, int height_in_blocks, size_t pitch_bytes, uint32_t pixel_format, detexhipShard *shards, int n_shards,
+		int gather_device, void *d_gathered, float *decode_wall_ms, float *gather_wall_ms) {
+	const char *who = "detexhipDecompressTextureLinearMultiDevice";
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f || !pixel_format_accepted(texture_format, pixel_format)) {
+		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who, texture_format, pixel_format);
+		return 1;
+	}
+	if (!shards || n_shards < 1 || n_shards > 64 || width < 0 || height < 0 || width_in_blocks < 0 || height_in_blocks < 0 ||
+			(gather_device >= 0 && !d_gathered)) {
+		detexSetErrorMessage("%s: bad arguments (1..64 shards, non-negative geometry, d_gathered with gather_device)", who);
+		return 1;
+	}
+	const size_t px = (size_t)detexGetPixelSize(pixel_format), bs = detexGetCompressedBlockSize(texture_format);
+	const size_t pitch = pitch_bytes ? pitch_bytes : (size_t)width * px;
+	const size_t wb = (size_t)width_in_blocks;
+	std::lock_guard<std::mutex> lock(g_multi_mutex);
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	int rc = 0;
+	auto fail = [&](const char *what, hipError_t e) { detexSetErrorMessage("%s: %s failed: %s", who, what, hipGetErrorString(e)); rc = 1; };
+	// per-shard rows, streams, status words, uploads
+	for (int g = 0; g < n_shards && rc == 0; g++) {
+		detexhipShard &sh = shards[g];
+		(void)detexhipShardRows(height_in_blocks, n_shards, g, &sh.row0, &sh.row1);
+		sh.decode_ms = 0.f; sh.invalid_blocks = 0;
+		ShardSlot &sl = g_shard_slots[g];
+		hipError_t e = prepare_slot(sl, sh.device);
+		if (e != hipSuccess) { fail("device / stream setup", e); break; }
+		if ((e = hipMemsetAsync(sl.d_status, 0, 4, sl.stream)) != hipSuccess) { fail("hipMemsetAsync", e); break; }
+		const size_t n = (size_t)(sh.row1 - sh.row0) * wb * bs;
+		if (!sh.d_blocks) {
+			if (!host_blocks) { detexSetErrorMessage("%s: shard %d has no d_blocks and host_blocks is NULL", who, g); rc = 1; break; }
+			if ((e = hipMalloc(&sl.d_upload, n ? n : 16)) != hipSuccess) { fail("hipMalloc(blocks)", e); break; }
+			if (n && (e = hipMemcpyAsync(sl.d_upload, static_cast<const uint8_t *>(host_blocks) + (size_t)sh.row0 * wb * bs, n, hipMemcpyHostToDevice,
+					sl.stream)) != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
+		}
+		if (gather_device >= 0 && sh.device != gather_device) {		// direct peer copies over xGMI where the topology allows
+			e = hipDeviceEnablePeerAccess(gather_device, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();	// not fatal: hipMemcpyPeerAsync then stages the copy
+		}
+	}
+	for (int g = 0; g < n_shards && rc == 0; g++) {		// uploads done: the timed region starts with idle devices
+		hipError_t e = hipSetDevice(shards[g].device);
+		if (e == hipSuccess) e = hipStreamSynchronize(g_shard_slots[g].stream);
+		if (e != hipSuccess) fail("hipStreamSynchronize", e);
+	}
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int g = 0; g < n_shards && rc == 0; g++) {
+		detexhipShard &sh = shards[g];
+		ShardSlot &sl = g_shard_slots[g];
+		hipError_t e = hipSetDevice(sh.device);
+		if (e != hipSuccess) { fail("hipSetDevice", e); break; }
+		const size_t y0 = (size_t)sh.row0 * 4u, y1 = ((size_t)sh.row1 * 4u < (size_t)height) ? (size_t)sh.row1 * 4u : (size_t)height;
+		(void)hipEventRecord(sl.e0, sl.stream);
+		if (y1 > y0 && sh.row1 > sh.row0) {
+			if (detexhipDecompressTextureLinearDevice(texture_format, sh.d_blocks ? sh.d_blocks : sl.d_upload, width, (int)(y1 - y0), width_in_blocks,
+					sh.row1 - sh.row0, sh.d_pixels, pitch, pixel_format, sl.stream, sl.d_status) != 0) { rc = 1; break; }
+		}
+		(void)hipEventRecord(sl.e1, sl.stream);
+		if (gather_device >= 0 && y1 > y0) {
+			e = hipMemcpyPeerAsync(static_cast<uint8_t *>(d_gathered) + y0 * pitch, gather_device, sh.d_pixels, sh.device, (y1 - y0) * pitch, sl.stream);
+			if (e != hipSuccess) { fail("hipMemcpyPeerAsync", e); break; }
+		}
+		(void)hipEventRecord(sl.e2, sl.stream);
+	}
+	if (rc == 0) {
+		for (int g = 0; g < n_shards; g++) { (void)hipSetDevice(shards[g].device); hipError_t e = hipEventSynchronize(g_shard_slots[g].e1); if (e != hipSuccess && rc == 0) fail("kernel", e); }
+		const auto t1 = std::chrono::steady_clock::now();
+		for (int g = 0; g < n_shards; g++) { (void)hipSetDevice(shards[g].device); hipError_t e = hipEventSynchronize(g_shard_slots[g].e2); if (e != hipSuccess && rc == 0) fail("gather", e); }
+		const auto t2 = std::chrono::steady_clock::now();
+		if (decode_wall_ms) *decode_wall_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+		if (gather_wall_ms) *gather_wall_ms = gather_device >= 0 ? std::chrono::duration<float, std::milli>(t2 - t0).count() : 0.f;
+		for (int g = 0; g < n_shards && rc == 0; g++) {
+			(void)hipSetDevice(shards[g].device);
+			uint32_t st = 0;
+			hipError_t e = hipMemcpy(&st, g_shard_slots[g].d_status, 4, hipMemcpyDeviceToHost);
+			if (e != hipSuccess) { fail("hipMemcpy(status)", e); break; }
+			shards[g].invalid_blocks = st != 0;
+			(void)hipEventElapsedTime(&shards[g].decode_ms, g_shard_slots[g].e0, g_shard_slots[g].e1);
+		}
+	}
+	for (int g = 0; g < n_shards; g++) {
+		ShardSlot &sl = g_shard_slots[g];
+		if (sl.d_upload) { (void)hipSetDevice(sl.device); (void)hipStreamSynchronize(sl.stream); (void)hipFree(sl.d_upload); sl.d_upload = nullptr; }
+	}
+	if (prev >= 0) (void)hipSetDevice(prev);
+	return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,11 +718,23 @@ extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_
 }
 
 // shared body of the two texture drivers (texture.c:77-98, 105-145)
+//
+// upload -> one launch -> download on the thread's stream.  The PCIe download of the pixels bounds this tier (8192^2
+// BC1: 256 MiB at the 56 GB/s pageable copies reach on the test box = 4.8 ms; upload 0.6 ms, kernel 0.04 ms: 5.4 ms).
+// A band pipeline (upload k+1 | kernel k | download k-1 on three streams, uploads from a helper thread because
+// hipMemcpyAsync on pageable memory blocks its caller) was built and measured: 5.40 vs 5.45 ms -- a download that
+// shares the link with an upload runs at 41-50 GB/s instead of 56 and every extra copy call costs 30-50 us
+// (tools/ubench/host_paths.hip) -- so it was not kept.
 static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format, bool tiled) {
 	const char *who = tiled ? "detexDecompressTextureTiled" : "detexDecompressTextureLinear";
 	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	if (texture->width < 0 || texture->height < 0 || texture->width_in_blocks < 0 || texture->height_in_blocks < 0) {
+		detexSetErrorMessage("%s: negative texture dimensions", who);
+		return false;
+	}
 	const size_t wb = (size_t)texture->width_in_blocks, hb = (size_t)texture->height_in_blocks;
-	const size_t out_bytes = tiled ? wb * hb * 16u * px : (size_t)texture->width * (size_t)texture->height * px;
+	const size_t width = (size_t)texture->width, height = (size_t)texture->height;
+	const size_t out_bytes = tiled ? wb * hb * 16u * px : width * height * px;
 	if (!detexFormatIsCompressed(texture->format)) {
 		if (tiled) { detexSetErrorMessage("detexDecompressTextureTiled: Cannot handle uncompressed texture format"); return false; }
 		// texture.c:108-111 hands uncompressed textures to detexConvertPixels; only its identity
@@ -561,21 +757,30 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	if (out_bytes == 0 || wb * hb == 0) return true;
 	if (!context_ready()) return false;
 	ThreadContext &c = t_ctx;
-	const size_t in_bytes = wb * hb * detexGetCompressedBlockSize(texture->format);
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	const size_t bs = detexGetCompressedBlockSize(texture->format);
+	const size_t in_bytes = wb * hb * bs;
+	// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
+	// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
+	const size_t cov_w = tiled ? 0 : (width < 4u * wb ? width : 4u * wb), cov_h = tiled ? 0 : (height < 4u * hb ? height : 4u * hb);
 	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, out_bytes)) return false;
 	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
-	HIP_TRY(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);
+	uint32_t status = 0;
+	HIP_TRY(hipMemcpyAsync(d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
 	int rc;
 	if (tiled)
-		rc = detexhipDecompressTextureTiledDevice(texture->format, c.d_in, texture->width_in_blocks, texture->height_in_blocks,
-			c.d_out, pixel_format, c.stream, c.d_status);
+		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, c.d_status);
 	else
-		rc = detexhipDecompressTextureLinearDevice(texture->format, c.d_in, texture->width, texture->height,
-			texture->width_in_blocks, texture->height_in_blocks, c.d_out, (size_t)texture->width * px, pixel_format, c.stream,
-			c.d_status);
+		rc = detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format,
+			c.stream, c.d_status);
 	if (rc != 0) return false;
-	uint32_t status = 0;
-	HIP_TRY(hipMemcpyAsync(pixel_buffer, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	if (tiled || (cov_w == width && cov_h == height)) {
+		HIP_TRY(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	} else if (cov_w > 0 && cov_h > 0) {
+		HIP_TRY(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)");
+	}
 	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 	if (status != 0) {
@@ -603,6 +808,8 @@ extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *text
 	}
 	if (!context_ready()) return false;
 	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
 	const size_t bs = detexGetCompressedBlockSize(format);
 	size_t in_off[kMaxLevels], out_off[kMaxLevels], in_total = 0, out_total = 0;
 	for (int l = 0; l < n_textures; l++) {
@@ -642,6 +849,8 @@ extern "C" bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *bl
 	if (!f) { detexSetErrorMessage("detexhipModeHistogram: 0x%08X is not a block-compressed format of this library", texture_format); return false; }
 	if (!context_ready()) return false;
 	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
 	const size_t nbytes = n_blocks * detexGetCompressedBlockSize(texture_format);
 	if (!reserve(&c.d_in, &c.in_cap, nbytes ? nbytes : 256)) return false;
 	if (nbytes) HIP_TRY(hipMemcpyAsync(c.d_in, blocks, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
@@ -658,6 +867,15 @@ extern "C" bool detexDecompressTextureTiled(const detexTexture *texture, uint8_t
 
 extern "C" bool detexDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
 	return decompress_texture(texture, pixel_buffer, pixel_format, false);
+}
+
+// The same two drivers under names that do not collide with the reference's: for a libdetex that forwards its own
+// detexDecompressTextureLinear / Tiled here while both libraries are linked.
+extern "C" bool detexhipHostDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, false);
+}
+extern "C" bool detexhipHostDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, true);
 }
 
 // ------------------------------------------------------------------------------------------------

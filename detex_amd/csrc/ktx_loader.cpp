@@ -68,36 +68,53 @@ extern "C" bool detexLoadKTXFileWithMipmaps(const char *filename, int max_mipmap
 		return false;
 	}
 	const size_t block_bytes = detexGetCompressedBlockSize(texture_format);
-	int width = (int)header[9], height = (int)header[10];
-	if (height == 0) height = 1;
-	int levels = (int)header[14] < 1 ? 1 : (int)header[14];
+	// The header is file content: dimensions are range-checked before any arithmetic (the decode entry points take at
+	// most 32768 x 32768; the reference reads them unchecked, ktx.c:73-75) and every size is computed in 64 bits.
+	const uint32_t w32 = header[9], h32 = header[10] == 0 ? 1u : header[10];
+	if (w32 == 0 || w32 > 32768u || h32 > 32768u) {
+		detexSetErrorMessage("detexLoadKTXFileWithMipmaps: Error loading file %s: texture size %ux%u is outside 1..32768", filename,
+			(unsigned)w32, (unsigned)h32);
+		fclose(f);
+		return false;
+	}
+	int width = (int)w32, height = (int)h32;
+	int levels = (int)header[14] < 1 || header[14] > 32u ? (header[14] > 32u ? 32 : 1) : (int)header[14];
 	if (levels > max_mipmaps) levels = max_mipmaps;
 	if (levels < 1) { fclose(f); detexSetErrorMessage("detexLoadKTXFileWithMipmaps: max_mipmaps must be at least 1"); return false; }
-	if (header[15] > 0 && fseek(f, (long)header[15], SEEK_CUR) != 0) return fail_read();	// key/value data (:99-107)
+	if (header[15] > 0) {							// key/value data (:99-107): must really be there
+		const long here = ftell(f);
+		if (here < 0 || fseek(f, 0, SEEK_END) != 0) return fail_read();
+		const long end = ftell(f);
+		if (end < 0 || (uint64_t)header[15] > (uint64_t)(end - here) || fseek(f, here + (long)header[15], SEEK_SET) != 0) return fail_read();
+	}
 	detexTexture **textures = static_cast<detexTexture **>(calloc((size_t)levels, sizeof(detexTexture *)));
+	if (!textures) return fail_read();
 	for (int i = 0; i < levels; i++) {
 		uint32_t image_size;
 		if (fread(&image_size, 1, 4, f) != 4) { free_levels(textures, levels); return fail_read(); }
 		if (swapped) image_size = bswap(image_size);
 		const int wb = (width + 3) / 4, hb = (height + 3) / 4;
-		const size_t need = (size_t)wb * (size_t)hb * block_bytes;
-		if (image_size != need) {
+		const uint64_t need = (uint64_t)wb * (uint64_t)hb * (uint64_t)block_bytes;
+		if ((uint64_t)image_size != need) {
 			detexSetErrorMessage("detexLoadKTXFileWithMipmaps: Error loading file %s: Image size field of mipmap level %d "
 				"does not match (%d vs %d)", filename, i, (int)image_size, (int)need);
 			free_levels(textures, levels);
 			fclose(f);
 			return false;
 		}
-		detexTexture *t = static_cast<detexTexture *>(malloc(sizeof(detexTexture)));
+		detexTexture *t = static_cast<detexTexture *>(calloc(1, sizeof(detexTexture)));
+		if (!t) { free_levels(textures, levels); return fail_read(); }
 		textures[i] = t;
 		t->format = texture_format;
-		t->data = static_cast<uint8_t *>(malloc(need ? need : 1));
+		t->data = static_cast<uint8_t *>(malloc(need ? (size_t)need : 1));
+		if (!t->data) { free_levels(textures, levels); return fail_read(); }
 		t->width = width; t->height = height; t->width_in_blocks = wb; t->height_in_blocks = hb;
-		if (fread(t->data, 1, need, f) != need) { free_levels(textures, levels); return fail_read(); }
+		if (fread(t->data, 1, (size_t)need, f) != (size_t)need) { free_levels(textures, levels); return fail_read(); }
 		width >>= 1; height >>= 1;			// next level, rounding down (:160-163)
 		if (i + 1 < levels) {				// mipPadding (:166-175)
 			const long pad = 3 - (long)((image_size + 3) % 4);
-			if (pad > 0 && fseek(f, pad, SEEK_CUR) != 0) { free_levels(textures, levels); return fail_read(); }
+			char padding[4];
+			if (pad > 0 && fread(padding, 1, (size_t)pad, f) != (size_t)pad) { free_levels(textures, levels); return fail_read(); }
 		}
 	}
 	fclose(f);

@@ -27,16 +27,22 @@ extern "C" {
 
 #define DETEXHIP_API __attribute__((visibility("default")))
 
-/* Library / device management.  The device is per calling thread, like hipSetDevice. */
+/* Library / device management.  detexhipSetDevice selects the GPU the HOST-POINTER tier of the calling thread
+ * uses (default: DETEXHIP_DEVICE or 0); it does not change the thread's current HIP device -- the host tier
+ * switches to its device for the duration of each call and restores the caller's.  The device tier below runs
+ * wherever the caller's stream lives.  detexhipReleaseThreadResources frees the calling thread's staging
+ * buffers, streams and events (they are re-created on the next host-tier call; a thread that decoded one
+ * 32768^2 texture otherwise keeps 4.5 GiB of device memory for its lifetime). */
 DETEXHIP_API int detexhipGetDeviceCount(void);
 DETEXHIP_API int detexhipSetDevice(int device);
+DETEXHIP_API void detexhipReleaseThreadResources(void);
 DETEXHIP_API const char *detexhipVersion(void);
 
 /*
  * Device-resident counterpart of detexDecompressTextureLinear (texture.c:105-145).
  *   texture_format   DETEX_TEXTURE_FORMAT_* (detex.h:613-727)
  *   d_blocks         width_in_blocks*height_in_blocks blocks of 8/16 bytes, row-major
- *                    (texture.c:141), 8/16-byte aligned
+ *                    (texture.c:141), 8/16-byte aligned (checked: rc != 0 otherwise)
  *   width,height     image size in pixels; blocks are clipped to it (texture.c:116-136)
  *   d_pixels         row-major image, row r at d_pixels + r*pitch_bytes
  *   pitch_bytes      >= width*pixel_size; the reference's layout is exactly width*pixel_size.
@@ -57,8 +63,37 @@ DETEXHIP_API int detexhipDecompressTextureLinearDevice(uint32_t texture_format, 
 	int width, int height, int width_in_blocks, int height_in_blocks,
 	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status);
 
+/*
+ * One texture over several devices (the reference stores blocks row-major and writes a row-major
+ * image, texture.c:115-141, so a band of block rows is ONE contiguous input range and ONE contiguous output
+ * range -- the decode needs no exchange between devices).  Shard g of n decodes block rows
+ * [g*hb/n, (g+1)*hb/n) (detexhipShardRows) on shards[g].device, from shards[g].d_blocks (that band's blocks,
+ * resident on the device) or, when NULL, from the band's slice of host_blocks, uploaded by the call; into
+ * shards[g].d_pixels (that band's rows, pitch_bytes apart; 0 = width*pixel_size).  One calling thread drives
+ * all devices: per-shard streams, kernels launched back to back, HIP events for the per-device kernel time.
+ * gather_device >= 0 additionally copies every band into the whole image d_gathered on that device with
+ * hipMemcpyPeerAsync (direct xGMI transfers, one per source device, so all links of the root are busy);
+ * it is timed separately and is never part of the decode time.  The call returns after everything completed:
+ * 0 = ran (the reference's bool result is "no shard has invalid_blocks"), non-zero = usage / HIP error.
+ * *decode_wall_ms: host clock from the first launch until the last kernel finished (uploads excluded);
+ * *gather_wall_ms: the same clock until the last peer copy finished.  Serialised by an internal mutex.
+ */
+typedef struct {
+	int device;			/* in */
+	const void *d_blocks;		/* in: the shard's blocks on `device`, or NULL (uploaded from host_blocks) */
+	void *d_pixels;			/* in: the shard's band of the image on `device` */
+	int row0, row1;			/* out: block rows [row0, row1) */
+	float decode_ms;		/* out: kernel time on this device (HIP events) */
+	int invalid_blocks;		/* out: 1 if a block of the band was invalid (zero-filled, texture.c:125-128) */
+} detexhipShard;
+DETEXHIP_API int detexhipShardRows(int height_in_blocks, int n_shards, int shard, int *row0, int *row1);
+DETEXHIP_API int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_format, const void *host_blocks,
+	int width, int height, int width_in_blocks, int height_in_blocks, size_t pitch_bytes, uint32_t pixel_format,
+	detexhipShard *shards, int n_shards, int gather_device, void *d_gathered,
+	float *decode_wall_ms, float *gather_wall_ms);
+
 /* Device-resident counterpart of detexDecompressTextureTiled (texture.c:77-98): block i
- * occupies 16*pixel_size contiguous bytes of d_pixels; no clipping. */
+ * occupies 16*pixel_size contiguous bytes of d_pixels (16-byte aligned); no clipping. */
 DETEXHIP_API int detexhipDecompressTextureTiledDevice(uint32_t texture_format, const void *d_blocks,
 	int width_in_blocks, int height_in_blocks, void *d_pixels, uint32_t pixel_format,
 	void *stream, uint32_t *d_status);
@@ -93,6 +128,12 @@ DETEXHIP_API int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, c
 DETEXHIP_API bool detexhipDecompressTexturesLinear(const detexTexture *const *textures, int n_textures,
 	uint8_t *const *pixel_buffers, uint32_t pixel_format);
 
+/* detexDecompressTextureLinear / detexDecompressTextureTiled of this library under names that do not collide
+ * with the reference's: what a libdetex that forwards its own drivers to the GPU would call when both
+ * libraries are linked. */
+DETEXHIP_API bool detexhipHostDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format);
+DETEXHIP_API bool detexhipHostDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format);
+
 /* ---- block-mode histogram -----------------------------------------------------
  * histogram[m] = number of blocks for which the reference's detexGetMode<FMT> returns m
  * (decompress-bc.c:63-69, decompress-etc.c:183-190,370-395,721-742, decompress-bptc.c:603-610,
@@ -104,16 +145,10 @@ DETEXHIP_API int detexhipModeHistogramDevice(uint32_t texture_format, const void
 DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,
 	uint32_t histogram[16]);
 
-/* Kernel-variant selection for A/B measurements (bench.py --variant):
- *   0  lane-per-block, 64x1-block wave tiles, non-temporal row stores (default)
- *   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)   [BC1 only]
- *   2  as 0 with ordinary (cached) row stores (and no LDS row transpose for 64-bit pixels)
- *   3  as 0 with the alternative decoder: BPTC_FLOAT field scatter as a per-mode switch instead of
- *      descriptor words; BPTC texel stage selecting subset endpoints with v_bfi chains (no LDS rows)
- *   4  as 0, BPTC block fields extracted from registers instead of an LDS copy of the block
- *   5  BPTC with mode-sorted waves (workgroup counting sort by mode; measured slower, kept for the record)
- *   6  as 0 with XCD-contiguous tile order (each XCD decodes one contiguous eighth of the image)
- * Unknown values fall back to 0.  Per calling thread.  Also settable with DETEXHIP_VARIANT. */
+/* Kernel-variant selection for A/B measurements.  The product library has ONE kernel per
+ * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab,
+ * -DDETEXHIP_AB_VARIANTS; detex_amd/csrc/ab/ab_dispatch.h lists them).  Unknown values fall back to 0.
+ * Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);
 

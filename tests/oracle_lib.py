@@ -129,13 +129,13 @@ class DetexAPI:
         hb = (height + 3) // 4 if hb is None else hb
         return DetexTexture(fmt.texture_format, _ptr(data), width, height, wb, hb)
 
-    def linear(self, fmt, data, width, height, pixel_format=None, out=None):
+    def linear(self, fmt, data, width, height, pixel_format=None, out=None, wb=None, hb=None):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         pf = (fmt.texture_format & 0xFFFF) if pixel_format is None else pixel_format
         px = 1 + ((pf & 0xF00) >> 8)
         if out is None:
             out = np.zeros(width * height * px, np.uint8)
-        tex = self._texture(fmt, data, width, height)
+        tex = self._texture(fmt, data, width, height, wb, hb)
         ok = self.lib.detexDecompressTextureLinear(ctypes.byref(tex), _ptr(out), pf)
         return bool(ok), out
 

@@ -1,0 +1,153 @@
+"""GPU tests of the host-pointer tier's band pipeline, the device-context rules and the multi-device C entry
+(SURVEY.md 8b, 8e).  Everything goes through the C ABI; bit-exact against the oracle / the single-device call."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from detex_amd import formats as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda()
+
+
+@pytest.mark.parametrize("name,W,H", [("BC1", 8192, 4096), ("BPTC_FLOAT", 4096, 2048), ("RGTC1", 16384, 8192), ("BPTC", 4096, 4100), ("ETC2", 2050, 9000)])
+def test_host_tier_large_textures_match_device_tier(name, W, H, torch_cuda, hiplib):
+    """large textures (64-256 MiB of pixels), incl. clipped geometry: the host-pointer drop-in
+    entry == the device tier on the same stream, byte for byte, and the bool result agrees"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    data = ol.stream_u(fmt, wb * hb, seed=0x9057 + fmt.index)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    want = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+    torch.cuda.synchronize()
+    ok, got = hiplib.linear(fmt, data, W, H)
+    assert got.size == W * H * fmt.pixel_bytes
+    assert np.array_equal(got, want.cpu().numpy())
+    assert ok == bool(status.item() == 0)
+    # block-major layout through the same pipeline
+    if W % 4 == 0 and H % 4 == 0 and name in ("BC1", "BPTC_FLOAT"):
+        want_t = binding.decompress_tiled_device(fmt, _dev(torch, data), wb, hb)
+        torch.cuda.synchronize()
+        ok_t, got_t = hiplib.tiled(fmt, data, wb, hb)
+        assert np.array_equal(got_t, want_t.cpu().numpy()) and ok_t == ok
+
+
+def test_host_tier_leaves_uncovered_pixels_untouched(torch_cuda, hiplib, oracle):
+    """a block grid smaller than the image (width > 4*wb, height > 4*hb): the reference writes only covered pixels
+    (texture.c:116-136); the caller's other bytes must survive"""
+    fmt = F.BY_NAME["BC1"]
+    W, H, wb, hb = 70, 45, 16, 10                  # grid covers 64 x 40
+    data = ol.stream_u(fmt, wb * hb, seed=77)
+    out = np.full(W * H * 4, 0xA5, np.uint8)
+    ok, got = hiplib.linear(fmt, data, W, H, out=out, wb=wb, hb=hb)
+    img = got.reshape(H, W, 4)
+    _, want = oracle.linear(fmt, data, 64, 40)
+    assert np.array_equal(img[:40, :64].reshape(-1), want)
+    assert (img[40:] == 0xA5).all() and (img[:, 64:] == 0xA5).all()
+
+
+def test_release_thread_resources_and_reuse(torch_cuda, hiplib, oracle):
+    torch = torch_cuda
+    fmt = F.BY_NAME["BC3"]
+    W, H = 4096, 4096
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=5)
+    ok1, a = hiplib.linear(fmt, data, W, H)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    hiplib.lib.detexhipReleaseThreadResources.restype = None
+    hiplib.lib.detexhipReleaseThreadResources()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after - free_before >= W * H * 4            # the 64 MiB output staging buffer came back
+    ok2, b = hiplib.linear(fmt, data, W, H)                  # the context is rebuilt on demand
+    assert ok1 == ok2 and np.array_equal(a, b)
+    _, want = oracle.linear(fmt, data[:64 * (W // 4) * 16], W, 256)
+    assert np.array_equal(b[:want.size], want)
+
+
+def test_device_tier_rejects_misaligned_pointers(torch_cuda):
+    from detex_amd import binding
+    torch = torch_cuda
+    lib = binding.load()
+    fmt = F.BY_NAME["BPTC"]
+    buf = torch.zeros(64 * 16 + 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64 * 64 + 64, dtype=torch.uint8, device="cuda")
+    rc = lib.detexhipDecompressTextureLinearDevice(fmt.texture_format, buf.data_ptr() + 8, 32, 32, 8, 8, out.data_ptr(), 128, 0x334, None, None)
+    assert rc != 0 and b"16-byte aligned" in lib.detexGetErrorMessage()
+    rc = lib.detexhipDecompressTextureTiledDevice(fmt.texture_format, buf.data_ptr(), 8, 8, out.data_ptr() + 4, 0x334, None, None)
+    assert rc != 0 and b"aligned" in lib.detexGetErrorMessage()
+    rc = lib.detexhipDecompressTextureLinearDevice(fmt.texture_format, buf.data_ptr(), 32, 32, 8, 8, out.data_ptr(), 128, 0x334, None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+
+
+def test_set_device_rules(torch_cuda):
+    from detex_amd import binding
+    lib = binding.load()
+    n = lib.detexhipGetDeviceCount()
+    assert n >= 1
+    import torch
+    before = torch.cuda.current_device()
+    lib.detexhipReleaseThreadResources.restype = None
+    lib.detexhipReleaseThreadResources()                     # this thread may have used device 0 in earlier tests
+    assert lib.detexhipSetDevice(n + 3) != 0 and b"no such device" in lib.detexGetErrorMessage()
+    assert lib.detexhipSetDevice(0) == 0
+    out = np.zeros(16 * 4, np.uint8)
+    blk = np.arange(8, dtype=np.uint8)
+    lib.detexDecompressBlockBC1.restype = ctypes.c_bool
+    assert lib.detexDecompressBlockBC1(blk.ctypes.data_as(ctypes.c_void_p), 0xFFFFFFFF, 0, out.ctypes.data_as(ctypes.c_void_p))
+    # the context now lives on device 0: another device is refused BEFORE the thread's current device is touched
+    assert lib.detexhipSetDevice(1) != 0 and (b"already used" in lib.detexGetErrorMessage() or b"no such device" in lib.detexGetErrorMessage())
+    assert torch.cuda.current_device() == before             # selecting the host tier's device never moves the caller's
+
+
+@pytest.mark.parametrize("name,W,H,shards", [("BC1", 4096, 4096, None), ("BC1", 2048, 1000, 3), ("BPTC_FLOAT", 1024, 2048, 5), ("BPTC", 1024, 1028, 2), ("RGTC1", 512, 36, 8)])
+def test_multi_device_entry_matches_single_device(name, W, H, shards, torch_cuda, oracle):
+    """detexhipDecompressTextureLinearMultiDevice with n = device count (1 on the test box) and with several shards
+    placed on the same device: bands concatenated == the single-device call == the peer-gathered image; uploaded
+    host blocks and device-resident blocks give the same result; status per shard"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    ndev = binding.load().detexhipGetDeviceCount()
+    devices = list(range(ndev)) if shards is None else [g % ndev for g in range(shards)]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    data = ol.stream_u(fmt, wb * hb, seed=0x3017 + fmt.index + len(devices))
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    want = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status).cpu().numpy()
+    torch.cuda.synchronize()
+    r = binding.decompress_linear_multi_device(fmt, W, H, devices, host_blocks=data, gather_device=0)
+    got = np.concatenate([b.cpu().numpy()[:max(0, min(s[1] * 4, H) - s[0] * 4) * W * fmt.pixel_bytes] for b, s in zip(r["bands"], r["shards"])])
+    assert np.array_equal(got, want)
+    assert np.array_equal(r["gathered"].cpu().numpy(), want)
+    assert r["ok"] == bool(status.item() == 0)
+    assert [s[0] for s in r["shards"]][0] == 0 and r["shards"][-1][1] == hb
+    assert all(a[1] == b[0] for a, b in zip(r["shards"], r["shards"][1:]))
+    assert r["decode_wall_ms"] > 0 and all(s[2] >= 0 for s in r["shards"])
+    # blocks already resident on the devices
+    dblocks = []
+    for g, dev in enumerate(devices):
+        r0, r1 = r["shards"][g][0], r["shards"][g][1]
+        chunk = data[r0 * wb * fmt.block_bytes:r1 * wb * fmt.block_bytes]
+        dblocks.append(torch.from_numpy(np.ascontiguousarray(chunk) if chunk.size else np.zeros(16, np.uint8)).to("cuda:%d" % dev))
+    r2 = binding.decompress_linear_multi_device(fmt, W, H, devices, device_blocks=dblocks)
+    got2 = np.concatenate([b.cpu().numpy()[:max(0, min(s[1] * 4, H) - s[0] * 4) * W * fmt.pixel_bytes] for b, s in zip(r2["bands"], r2["shards"])])
+    assert np.array_equal(got2, want) and r2["gathered"] is None
+    # a sample of the result against the CPU oracle, so the comparison above is not GPU against GPU only
+    rows = min(hb, 8)
+    _, ref_rows = oracle.linear(fmt, data[:rows * wb * fmt.block_bytes], W, min(rows * 4, H))
+    assert np.array_equal(want[:ref_rows.size], ref_rows)

@@ -128,6 +128,25 @@ def test_ktx_loader_errors(tmp_path):
     q.write_bytes(bytes(raw))
     assert not ours.detexLoadKTXFile(str(q).encode(), ctypes.byref(tp))
     assert b"Unsupported format in .ktx file (glInternalFormat = 0x8058)" in ours.detexGetErrorMessage()
+    # hostile headers (file content is untrusted): negative / huge dimensions, metadata length past the end of the file
+    good = bytearray(open(os.path.join(GOLDEN, "test-texture-BC1.ktx"), "rb").read())
+    for off, val in ((36, 0xFFFFFFF8), (36, 0), (36, 40000), (40, 0xFFFFFFF8), (40, 0x7FFFFFFF)):
+        raw = bytearray(good)
+        raw[off:off + 4] = struct.pack("<I", val)
+        q = tmp_path / ("dim_%d_%x.ktx" % (off, val))
+        q.write_bytes(bytes(raw))
+        assert not ours.detexLoadKTXFile(str(q).encode(), ctypes.byref(tp)), (off, hex(val))
+        assert b"is outside 1..32768" in ours.detexGetErrorMessage(), ours.detexGetErrorMessage()
+    raw = bytearray(good)
+    raw[60:64] = struct.pack("<I", 1 << 30)                      # bytesOfKeyValueData far beyond the file
+    q = tmp_path / "kv.ktx"
+    q.write_bytes(bytes(raw))
+    assert not ours.detexLoadKTXFile(str(q).encode(), ctypes.byref(tp))
+    assert b"Error reading file" in ours.detexGetErrorMessage()
+    q = tmp_path / "short.ktx"
+    q.write_bytes(bytes(good[:64 + 4 + 100]))                    # payload truncated
+    assert not ours.detexLoadKTXFile(str(q).encode(), ctypes.byref(tp))
+    assert b"Error reading file" in ours.detexGetErrorMessage()
 
 
 @pytest.mark.skipif(not ol.have_ref(), reason="needs oracle/_ref")

@@ -38,6 +38,22 @@ int main() {
 		CK(hipStreamSynchronize(s0)); double done = now() - t;
 		printf("pageable async D2H: call returns after %.3f ms, complete after %.3f ms\n", issued * 1e3, done * 1e3);
 	}
+	for (int rep = 0; rep < 2; rep++) {	// pageable, 8 chunks of 32 MiB back to back on one stream
+		double t = now();
+		for (int k = 0; k < 8; k++) CK(hipMemcpyAsync(pageable_out + (size_t)k * (OUT / 8), (char *)d_out + (size_t)k * (OUT / 8), OUT / 8, hipMemcpyDeviceToHost, s0));
+		CK(hipStreamSynchronize(s0));
+		double a = now() - t;
+		printf("pageable D2H in 8 chunks of 32 MiB: %.3f ms (%.1f GB/s)\n", a * 1e3, OUT / a / 1e9);
+	}
+	for (int rep = 0; rep < 2; rep++) {	// two host threads: pageable H2D (32 MiB) while pageable D2H (256 MiB)
+		double t = now();
+		std::thread up([&] { CK(hipSetDevice(0)); CK(hipMemcpyAsync(d_in, pageable_in, IN, hipMemcpyHostToDevice, s1)); CK(hipStreamSynchronize(s1)); });
+		CK(hipMemcpyAsync(pageable_out, d_out, OUT, hipMemcpyDeviceToHost, s0)); CK(hipStreamSynchronize(s0));
+		double a = now() - t;
+		up.join();
+		double b = now() - t;
+		printf("pageable D2H 256 MiB with a second thread uploading 32 MiB: D2H done %.3f ms, both done %.3f ms\n", a * 1e3, b * 1e3);
+	}
 	for (int rep = 0; rep < 3; rep++) {
 		double t = now(); CK(hipHostRegister(pageable_out, OUT, hipHostRegisterDefault)); double reg = now() - t;
 		t = now(); CK(hipMemcpyAsync(pageable_out, d_out, OUT, hipMemcpyDeviceToHost, s0)); CK(hipStreamSynchronize(s0)); double cp = now() - t;
