@@ -45,7 +45,7 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 			return true;
 		}
 	}
-	if constexpr (ClassSorted<Dec>::kAvailable && Epilogue<EPI, Dec::kPixelBytes>::kRowDwords == 4) {
+	if constexpr (ClassSorted<Dec>::kAvailable && EpilogueOf<Dec, EPI>::kRowDwords == 4) {
 		if (g.variant == 5) {
 			hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 			*result = hipGetLastError();

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void decode_linear_sorted(const void *__restri
 	typedef ClassSorted<Dec> S;
 	typedef typename S::Word Word;
 	constexpr int P = Dec::kPixelBytes;
-	constexpr int ROW = Epilogue<EPI, P>::kRowDwords;
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	static_assert(P == 4 && ROW == 4, "32-bit pixels, 16-byte rows");
 	constexpr uint32_t kDead = S::kClasses;			// lanes past the end of the stream
 	static_assert(S::kClasses + 1 <= 16, "counter table");
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void decode_linear_sorted(const void *__restri
 		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
 	}
 	uint32_t o[4 * ROW];
-	Epilogue<EPI, P>::apply(d, o);
+	EpilogueOf<Dec, EPI>::apply(d, o);
 	// 4. rows back to the lane that owns the block's place in the image
 #pragma unroll
 	for (int r = 0; r < 4; r++) stage[r][owner] = v4{ o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3] };

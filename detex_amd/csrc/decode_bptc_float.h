@@ -238,7 +238,7 @@ DH uint32_t bc6h_sign_magnitude_pk(uint32_t p) {
 // SWITCH_SCATTER = true keeps the per-mode switch (cheaper when a whole wave shares one mode); the
 // default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
-	static constexpr int kBlockBytes = 16, kPixelBytes = 8;
+	static constexpr int kBlockBytes = 16, kPixelBytes = 8, kNative = SIGNED ? kNatOther : kNatFloatRGBX16;
 	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626

@@ -327,21 +327,21 @@ struct DecETC2EAC {
 };
 struct DecEACR11 {
 	static DH void prepare() { eac_prepare(); }
-	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
+	static constexpr int kBlockBytes = 8, kPixelBytes = 2, kNative = kNatR16;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return eac11_channel<false>(blk.x, blk.y, d);
 	}
 };
 struct DecEACSignedR11 {
 	static DH void prepare() { eac_prepare(); }
-	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
+	static constexpr int kBlockBytes = 8, kPixelBytes = 2, kNative = kNatSignedR16;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return eac11_channel<true>(blk.x, blk.y, d);
 	}
 };
 template <bool SIGNED> struct DecEACRG11T {
 	static DH void prepare() { eac_prepare(); }
-	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
+	static constexpr int kBlockBytes = 16, kPixelBytes = 4, kNative = SIGNED ? kNatSignedRG16 : kNatRG16;
 	// decompress-eac.c:144-157, 217-231: texel = R16 | G16 << 16
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {
 		uint32_t r[8], g[8];

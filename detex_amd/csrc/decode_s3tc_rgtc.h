@@ -221,7 +221,7 @@ DH bool rgtc_channel_s16(uint32_t w0, uint32_t w1, uint32_t (&pairs)[8]) {
 }
 
 struct DecRGTC1 {
-	static constexpr int kBlockBytes = 8, kPixelBytes = 1;
+	static constexpr int kBlockBytes = 8, kPixelBytes = 1, kNative = kNatR8;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[4]) {
 		rgtc_channel_u8(blk.x, blk.y, d);
 		return true;
@@ -229,7 +229,7 @@ struct DecRGTC1 {
 };
 
 struct DecRGTC2 {
-	static constexpr int kBlockBytes = 16, kPixelBytes = 2;
+	static constexpr int kBlockBytes = 16, kPixelBytes = 2, kNative = kNatRG8;
 	// decompress-rgtc.c:72-77: R from bytes 0-7, G from bytes 8-15, interleaved R,G
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		uint32_t r[4], g[4];
@@ -246,7 +246,7 @@ struct DecRGTC2 {
 
 struct DecSignedRGTC1 {
 	static DH void prepare() { rgtc_signed_prepare(); }
-	static constexpr int kBlockBytes = 8, kPixelBytes = 2;
+	static constexpr int kBlockBytes = 8, kPixelBytes = 2, kNative = kNatSignedR16;
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[8]) {
 		return rgtc_channel_s16(blk.x, blk.y, d);
 	}
@@ -254,7 +254,7 @@ struct DecSignedRGTC1 {
 
 struct DecSignedRGTC2 {
 	static DH void prepare() { rgtc_signed_prepare(); }
-	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
+	static constexpr int kBlockBytes = 16, kPixelBytes = 4, kNative = kNatSignedRG16;
 	// decompress-rgtc.c:141-147: texel = R16 | G16 << 16
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {
 		uint32_t r[8], g[8];

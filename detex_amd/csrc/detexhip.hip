@@ -74,15 +74,24 @@ struct BatchArgs {
 	hipStream_t stream; bool checked; int epi;
 };
 
-// which in-kernel pixel-format epilogues a decoder supports: the RGBA8-class
-// formats take BGRA8/BGRX8 and RGB8 targets, unsigned BC6H takes FLOAT_BGRX16
-template <class Dec> constexpr int target_class() {
-	if (std::is_same_v<Dec, DecBC1> || std::is_same_v<Dec, DecBC1A> || std::is_same_v<Dec, DecBC2> || std::is_same_v<Dec, DecBC3> ||
-			std::is_same_v<Dec, DecBPTC> || std::is_same_v<Dec, DecETC1> || std::is_same_v<Dec, DecETC2> ||
-			std::is_same_v<Dec, DecETC2Punchthrough> || std::is_same_v<Dec, DecETC2EAC>)
-		return 1;
-	if (std::is_same_v<Dec, DecBPTCFloat>) return 2;
-	return 0;
+// Calls fn(std::integral_constant<int, EPI>) for the epilogue `epi` if the decoder's native pixel class can feed it
+// (kernels.h: RGBA8-class natives take the R<->B swap and the RGB8 packing; 1/2-component natives and unsigned BC6H
+// the three "to 8-bit RGB(X)" epilogues; BC6H also its own R<->B swap); hipErrorInvalidValue otherwise.
+template <class Dec, class F> hipError_t with_epilogue(int epi, F &&fn) {
+	constexpr int NC = NativeOf<Dec>::value;
+	if (epi == kEpiNone) return fn(std::integral_constant<int, kEpiNone>{});
+	if constexpr (NC == kNatRGBA8) {
+		if (epi == kEpiSwapRB8) return fn(std::integral_constant<int, kEpiSwapRB8>{});
+		if (epi == kEpiPackRGB8) return fn(std::integral_constant<int, kEpiPackRGB8>{});
+	} else if constexpr (NC != kNatOther) {
+		if constexpr (NC == kNatFloatRGBX16) {
+			if (epi == kEpiSwapRB16) return fn(std::integral_constant<int, kEpiSwapRB16>{});
+		}
+		if (epi == kEpiToRGBX8) return fn(std::integral_constant<int, kEpiToRGBX8>{});
+		if (epi == kEpiToBGRX8) return fn(std::integral_constant<int, kEpiToBGRX8>{});
+		if (epi == kEpiToRGB8) return fn(std::integral_constant<int, kEpiToRGB8>{});
+	}
+	return hipErrorInvalidValue;
 }
 
 // decoders whose throughput kernels carry wave-uniform specialisations use the plain form in the kernels that
@@ -129,7 +138,7 @@ constexpr int kMaxVariant = 0;
 #endif
 
 template <class Dec, int EPI> bool fast_geometry(const Geometry &g) {
-	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr unsigned row_bytes = 4u * EpilogueOf<Dec, EPI>::kRowDwords;
 	constexpr unsigned align = row_bytes % 16u == 0 ? 16u : (row_bytes % 8u == 0 ? 8u : 4u);
 	return (g.width & 3u) == 0 && (g.height & 3u) == 0 && g.wb * 4u == g.width && g.hb * 4u == g.height &&
 		(reinterpret_cast<uintptr_t>(g.pixels) % align) == 0 && (g.pitch % align) == 0;
@@ -155,14 +164,7 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 
 template <class Dec> hipError_t launch_linear(const Geometry &g) {
 	if (g.wb * g.hb == 0) return hipSuccess;
-	if constexpr (target_class<Dec>() == 1) {
-		if (g.epi == kEpiSwapRB8) return launch_linear_epi<Dec, kEpiSwapRB8>(g);
-		if (g.epi == kEpiPackRGB8) return launch_linear_epi<Dec, kEpiPackRGB8>(g);
-	}
-	if constexpr (target_class<Dec>() == 2) {
-		if (g.epi == kEpiSwapRB16) return launch_linear_epi<Dec, kEpiSwapRB16>(g);
-	}
-	return g.epi == kEpiNone ? launch_linear_epi<Dec, kEpiNone>(g) : hipErrorInvalidValue;
+	return with_epilogue<Dec>(g.epi, [&](auto epi) { return launch_linear_epi<Dec, decltype(epi)::value>(g); });
 }
 
 template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
@@ -182,20 +184,13 @@ template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 
 template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
 	if (a.n == 0) return hipSuccess;
-	if constexpr (target_class<Dec>() == 1) {
-		if (a.epi == kEpiSwapRB8) return launch_blocks_epi<Dec, kEpiSwapRB8>(a);
-		if (a.epi == kEpiPackRGB8) return launch_blocks_epi<Dec, kEpiPackRGB8>(a);
-	}
-	if constexpr (target_class<Dec>() == 2) {
-		if (a.epi == kEpiSwapRB16) return launch_blocks_epi<Dec, kEpiSwapRB16>(a);
-	}
-	return a.epi == kEpiNone ? launch_blocks_epi<Dec, kEpiNone>(a) : hipErrorInvalidValue;
+	return with_epilogue<Dec>(a.epi, [&](auto epi) { return launch_blocks_epi<Dec, decltype(epi)::value>(a); });
 }
 
 // 8f-3: all levels of a mip chain in one launch (kernels_extra.h)
 struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; };
 template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
-	constexpr unsigned row_bytes = 4u * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr unsigned row_bytes = 4u * EpilogueOf<Dec, EPI>::kRowDwords;
 	constexpr unsigned align = row_bytes % 16u == 0 ? 16u : (row_bytes % 8u == 0 ? 8u : 4u);
 	for (uint32_t l = 0; l < a.table.n_levels; l++) {
 		LevelDesc &lv = a.table.level[l];
@@ -209,14 +204,7 @@ template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
 	return hipGetLastError();
 }
 template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
-	if constexpr (target_class<Dec>() == 1) {
-		if (a.epi == kEpiSwapRB8) return launch_levels_epi<Dec, kEpiSwapRB8>(a);
-		if (a.epi == kEpiPackRGB8) return launch_levels_epi<Dec, kEpiPackRGB8>(a);
-	}
-	if constexpr (target_class<Dec>() == 2) {
-		if (a.epi == kEpiSwapRB16) return launch_levels_epi<Dec, kEpiSwapRB16>(a);
-	}
-	return a.epi == kEpiNone ? launch_levels_epi<Dec, kEpiNone>(a) : hipErrorInvalidValue;
+	return with_epilogue<Dec>(a.epi, [&](auto epi) { return launch_levels_epi<Dec, decltype(epi)::value>(a); });
 }
 
 // 8f-4: block-mode histogram (kernels_extra.h)
@@ -264,25 +252,84 @@ const FormatEntry *lookup_format(uint32_t texture_format) {
 	return kFormats[idx].texture_format == texture_format ? &kFormats[idx] : nullptr;
 }
 
-// Target pixel formats of the block-decode path and the epilogue that produces each (-1 = not
-// offered).  Native, the RGBX8 <-> RGBA8 no-op edge (convert.c:768-769, 1087-1092), and the
-// in-kernel epilogues of SURVEY.md 8f-2: BGRA8/BGRX8 (what validate.c:204-209 and detex-view.c
-// request), RGB8 (detex-convert.c:283-284) for the RGBA8-class formats; FLOAT_BGRX16 for BC6H.
-// Semantics checked against the compiled reference (tools/make_goldens.py).
+// Target pixel formats of the block-decode path and the epilogue that produces each (-1 = not offered): the native
+// one, the RGBX8 <-> RGBA8 no-op edge (convert.c:768-769, 1087-1092), and -- converted inside the kernel with the exact
+// result of the path detexConvertPixels takes (kernels.h) -- what the reference's callers request: BGRA8 / BGRX8
+// (validate.c:204-209, detex-view.c:182), RGB8 (detex-convert.c:283-284) and RGBA8 / RGBX8, for every format the
+// reference itself can convert (checked against the compiled reference: tools/make_goldens.py); FLOAT_BGRX16 for BC6H.
+// Like the reference, the signed 16-bit formats have no path to BGRA8 and BPTC_SIGNED_FLOAT none to any 8-bit format.
 enum : uint32_t { kPixelBGRA8 = 0x33C, kPixelBGRX8 = 0x328, kPixelRGB8 = 0x220, kPixelFloatBGRX16 = 0x2729 };
 int epilogue_for(uint32_t texture_format, uint32_t pixel_format) {
 	const uint32_t native = texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK;
 	if (pixel_format == native) return kEpiNone;
-	const bool n8 = native == DETEX_PIXEL_FORMAT_RGBA8 || native == DETEX_PIXEL_FORMAT_RGBX8;
-	if (n8) {
-		if (pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8) return kEpiNone;
-		if (pixel_format == kPixelBGRA8 || pixel_format == kPixelBGRX8) return kEpiSwapRB8;
-		if (pixel_format == kPixelRGB8) return kEpiPackRGB8;
-	}
+	const bool to_rgbx = pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8;
+	const bool to_bgrx = pixel_format == kPixelBGRA8 || pixel_format == kPixelBGRX8;
+	if (native == DETEX_PIXEL_FORMAT_RGBA8 || native == DETEX_PIXEL_FORMAT_RGBX8)
+		return to_rgbx ? kEpiNone : (to_bgrx ? kEpiSwapRB8 : (pixel_format == kPixelRGB8 ? kEpiPackRGB8 : -1));
 	if (native == DETEX_PIXEL_FORMAT_FLOAT_RGBX16 && pixel_format == kPixelFloatBGRX16) return kEpiSwapRB16;
+	const bool unsigned_small = native == DETEX_PIXEL_FORMAT_R8 || native == DETEX_PIXEL_FORMAT_RG8 || native == DETEX_PIXEL_FORMAT_R16 ||
+		native == DETEX_PIXEL_FORMAT_RG16 || native == DETEX_PIXEL_FORMAT_FLOAT_RGBX16;
+	const bool signed_small = native == DETEX_PIXEL_FORMAT_SIGNED_R16 || native == DETEX_PIXEL_FORMAT_SIGNED_RG16;
+	if (unsigned_small || signed_small) {
+		if (to_rgbx) return kEpiToRGBX8;
+		if (to_bgrx) return (signed_small && pixel_format == kPixelBGRA8) ? -1 : kEpiToBGRX8;
+		if (pixel_format == kPixelRGB8) return kEpiToRGB8;
+	}
 	return -1;
 }
 bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) { return epilogue_for(texture_format, pixel_format) >= 0; }
+
+// The FLOAT_RGBX16 -> 8-bit epilogues look each half up in kHalfToU8 (kernels.h).  Entry = the reference's
+// FLOAT_RGBX16 -> RGBX16 -> RGBX8 path: f = half as float (exact), clamped to 0..1 (detex.h:941-948); u16 =
+// lrintf(f * 65535.0f + 0.5f) with the multiply, the add and the conversion all rounding DOWN (half-float.c:304-312 sets
+// FE_DOWNWARD); u8 = (u16 + 127) * 255 / 65535 (convert.c:299-313).  The float operations are reproduced in double
+// (products and sums of these operands are exact there) and rounded down to float by hand, so the table does not depend
+// on this translation unit's floating-point environment.  tests/test_oracle_pin.py compares all 65536 entries' effect
+// with the compiled reference.
+float round_down_to_float(double v) {
+	float r = (float)v;
+	if ((double)r > v) r = nextafterf(r, -INFINITY);
+	return r;
+}
+uint8_t half_to_u8_entry(uint32_t h) {
+	const uint32_t sign = h >> 15, exponent = (h >> 10) & 31u, mantissa = h & 1023u;
+	double f;
+	if (exponent == 31u) f = 2.0;		// Inf clamps to 1, and so does every NaN in the reference build (gcc -Ofast; pinned exhaustively); BC6H never decodes to either
+	else if (exponent == 0u) f = ldexp((double)mantissa, -24);
+	else f = ldexp((double)(mantissa + 1024u), (int)exponent - 25);
+	if (sign && !(exponent == 31u && mantissa)) f = -f;	// (a NaN of either sign converts like +Inf)
+	const double clamped = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+	const float product = round_down_to_float(clamped * 65535.0);
+	const float sum = round_down_to_float((double)product + 0.5);
+	const uint32_t u16 = (uint32_t)floor((double)sum) & 0xFFFFu;
+	return (uint8_t)component16_to_8(u16);
+}
+std::mutex g_half_table_mutex;
+bool g_half_table_ready[64];
+hipError_t ensure_half_table() {
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lock(g_half_table_mutex);
+	if (g_half_table_ready[dev]) return hipSuccess;
+	static uint8_t table[65536];
+	static bool built = false;
+	if (!built) { for (uint32_t h = 0; h < 65536u; h++) table[h] = half_to_u8_entry(h); built = true; }
+	e = hipMemcpyToSymbol(HIP_SYMBOL(kHalfToU8), table, sizeof table, 0, hipMemcpyHostToDevice);
+	if (e == hipSuccess) g_half_table_ready[dev] = true;
+	return e;
+}
+// epilogue for a (format, target) pair that pixel_format_accepted() has admitted, with its device table in place
+// (-2 + error message if the table upload failed)
+int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format) {
+	const int epi = epilogue_for(texture_format, pixel_format);
+	if ((texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK) == DETEX_PIXEL_FORMAT_FLOAT_RGBX16 && epi >= kEpiToRGBX8) {
+		hipError_t e = ensure_half_table();
+		if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: half-float table upload failed: %s", hipGetErrorString(e)); return -2; }
+	}
+	return epi;
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-thread device context of the host-pointer tier: a stream and grow-only device staging buffers that
@@ -387,7 +434,9 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	uint8_t ok = 0;
 	auto run = [&]() -> bool {
 		HIP_TRY(hipMemcpyAsync(c.d_in, bitstring, bs, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
-		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true, epilogue_for(f->texture_format, pixel_format) };
+		const int epi = prepared_epilogue(f->texture_format, pixel_format);
+		if (epi == -2) return false;
+		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true, epi };
 		HIP_TRY(f->blocks(a), "kernel launch");
 		HIP_TRY(hipMemcpyAsync(host_out, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 		HIP_TRY(hipMemcpyAsync(&ok, d_ok, 1, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
@@ -427,6 +476,8 @@ extern "C" int detexhipSetDevice(int device) {
 
 extern "C" void detexhipReleaseThreadResources(void) { t_ctx.release(); }
 
+extern "C" uint8_t detexhipHalfFloatToUNorm8(uint16_t half_bits) { return half_to_u8_entry(half_bits); }
+
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.2 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
 extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= kMaxVariant) ? variant : 0; }
@@ -445,7 +496,8 @@ extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, con
 	const char *who = "detexhipDecompressLevelsLinearDevice";
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
-	const int epi = epilogue_for(texture_format, pixel_format);
+	const int epi = prepared_epilogue(texture_format, pixel_format);
+	if (epi == -2) return 1;
 	if (epi < 0) { detexSetErrorMessage("%s: pixel format 0x%08X is outside the block-decode path for format 0x%08X", who, pixel_format, texture_format); return 1; }
 	if (n_levels < 0 || n_levels > kMaxLevels || (n_levels > 0 && !levels)) { detexSetErrorMessage("%s: 0..%d levels per call", who, kMaxLevels); return 1; }
 	const size_t px = (size_t)detexGetPixelSize(pixel_format), palign = px == 3 ? 1 : (px < 4 ? px : 4);
@@ -509,8 +561,10 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 		detexSetErrorMessage("detexhipDecompressTextureLinearDevice: d_blocks must be %d-byte aligned", (int)detexGetCompressedBlockSize(texture_format));
 		return 1;
 	}
+	const int epi = prepared_epilogue(texture_format, pixel_format);
+	if (epi == -2) return 1;
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
-		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epilogue_for(texture_format, pixel_format) };
+		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epi };
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -539,9 +593,10 @@ extern "C" int detexhipDecompressTextureTiledDevice(uint32_t texture_format, con
 		return 1;
 	}
 	if (width_in_blocks < 0 || height_in_blocks < 0) { detexSetErrorMessage("detexhipDecompressTextureTiledDevice: bad geometry"); return 1; }
+	const int epi = lookup_format(texture_format) ? prepared_epilogue(texture_format, pixel_format) : kEpiNone;
+	if (epi == -2) return 1;
 	return blocks_device("detexhipDecompressTextureTiledDevice", texture_format, d_blocks,
-		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false,
-		epilogue_for(texture_format, pixel_format));
+		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false, epi);
 }
 
 extern "C" int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,

@@ -28,6 +28,18 @@
 
 namespace detexhip {
 
+// native pixel format of a decoder (Dec::kNative; decoders without the member decode to RGBA8 / RGBX8): selects the
+// pixel-format epilogues a decoder can feed (kernels.h)
+enum : int { kNatRGBA8 = 0, kNatR8, kNatRG8, kNatR16, kNatSignedR16, kNatRG16, kNatSignedRG16, kNatFloatRGBX16, kNatOther };
+
+// 16-bit component -> 8-bit as the reference converts it (convert.c:258-267, 299-313): (x + 127) * 255 / 65535.
+// floor(y / 65535) = (y + (y >> 16) + 1) >> 16 for every y = (x + 127) * 255, x < 65536 (checked exhaustively in
+// tests/test_host_logic.py)
+DETEX_HD uint32_t component16_to_8(uint32_t x) {
+	const uint32_t y = (x + 127u) * 255u;
+	return (y + (y >> 16) + 1u) >> 16;
+}
+
 // ---- exact small-domain unsigned division by multiply-shift (products < 2^24 * 2^16) -----
 DETEX_HD uint32_t div3_u(uint32_t x) { return (x * 43691u) >> 17; }  // exact for x < 98304
 DETEX_HD uint32_t div5_u(uint32_t x) { return (x * 52429u) >> 18; }  // exact for x < 81920

@@ -37,40 +37,78 @@ template <int BYTES> struct BlockWord;
 template <> struct BlockWord<8> { using type = uint2; };
 template <> struct BlockWord<16> { using type = uint4; };
 
-// ---- in-register pixel-format epilogues (reference: convert.c:37-52, 54-70, 671-684) ----------
+// ---- in-register pixel-format epilogues (reference: detexConvertPixels, convert.c) ----------------------------
+// What the reference's callers ask detexDecompressTextureLinear for (BGRA8 / BGRX8: validate.c:204-209, detex-view.c:182;
+// RGB8: detex-convert.c:283-284) is produced inside the decode kernel, with the exact result of the conversion path
+// detexMatchConversion picks (convert.c:885-1063):
+//   RGBA8 / RGBX8 natives   R<->B swap keeps byte 3 (:37-52); RGB8 drops it (:671-684)
+//   R8, RG8                 -> RGBX8 (R, G or 0, 0, 0xFF) (:219-243), then as above
+//   R16, RG16               -> R8 / RG8 by (x + 127) * 255 / 65535 (:258-281), then as R8 / RG8
+//   SIGNED_R16 / RG16       -> R16 / RG16 by + 32768 (:158-181), then as R16 / RG16 (no path to BGRA8 in the reference: refused)
+//   FLOAT_RGBX16 (BC6H)     -> RGBX16 by lrintf(clamp01(f) * 65535 + 0.5) rounding down (half-float.c:304-312) -> RGBX8 by
+//                              the same 16 -> 8 map (:299-313): one 64 KiB lookup table per device (kHalfToU8)
+//                              FLOAT_BGRX16: swap halves 0 and 2 (:54-70)
 enum : int {
 	kEpiNone = 0,		// native pixel format (or the RGBX8 <-> RGBA8 no-op, convert.c:768-769)
-	kEpiSwapRB8 = 1,	// RGBA8/RGBX8 -> BGRA8/BGRX8: swap bytes 0 and 2, keep byte 3 (convert.c:37-52)
-	kEpiPackRGB8 = 2,	// RGBA8/RGBX8 -> RGB8: drop byte 3, 4 pixels -> 3 dwords (convert.c:671-684)
-	kEpiSwapRB16 = 3,	// FLOAT_RGBX16 -> FLOAT_BGRX16: swap halves 0 and 2 (convert.c:54-70)
+	kEpiSwapRB8 = 1,	// RGBA8/RGBX8 -> BGRA8/BGRX8
+	kEpiPackRGB8 = 2,	// RGBA8/RGBX8 -> RGB8: 4 pixels -> 3 dwords
+	kEpiSwapRB16 = 3,	// FLOAT_RGBX16 -> FLOAT_BGRX16
+	kEpiToRGBX8 = 4,	// 1/2-component and half-float natives -> RGBX8 / RGBA8 (4th byte 0xFF)
+	kEpiToBGRX8 = 5,	//                                   ... -> BGRX8 / BGRA8
+	kEpiToRGB8 = 6,		//                                   ... -> RGB8
 };
-template <int EPI, int P> struct Epilogue;
-template <int P> struct Epilogue<kEpiNone, P> {
+template <class Dec, class = void> struct NativeOf { static constexpr int value = kNatRGBA8; };
+template <class Dec> struct NativeOf<Dec, std::void_t<decltype(Dec::kNative)>> { static constexpr int value = Dec::kNative; };
+
+// half bit pattern -> 8-bit component of the FLOAT_RGBX16 -> RGBX16 -> RGBX8 path; filled per device by the host side
+// of the library before the first launch that needs it (detexhip.hip: ensure_half_table)
+__device__ uint8_t kHalfToU8[65536];
+
+// pixel i (0..15) of a decoded block as R | G << 8 | B << 16 | 0xFF << 24
+template <int NC> DH uint32_t pixel_as_rgbx8(const uint32_t *d, int i) {
+	if constexpr (NC == kNatR8) return perm(0u, d[i >> 2], 0x0D0C0C00u + (uint32_t)(i & 3));
+	else if constexpr (NC == kNatRG8) return perm(0u, d[i >> 1], 0x0D0C0000u | ((uint32_t)(2 * (i & 1) + 1) << 8) | (uint32_t)(2 * (i & 1)));
+	else if constexpr (NC == kNatR16 || NC == kNatSignedR16) {
+		const uint32_t x = ((d[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) ^ (NC == kNatSignedR16 ? 0x8000u : 0u);
+		return component16_to_8(x) | 0xFF000000u;
+	} else if constexpr (NC == kNatRG16 || NC == kNatSignedRG16) {
+		const uint32_t w = d[i] ^ (NC == kNatSignedRG16 ? 0x80008000u : 0u);
+		return component16_to_8(w & 0xFFFFu) | (component16_to_8(w >> 16) << 8) | 0xFF000000u;
+	} else {	// kNatFloatRGBX16: pixel = {R | G << 16, B | X << 16}
+		const uint32_t w0 = d[2 * i], w1 = d[2 * i + 1];
+		return (uint32_t)kHalfToU8[w0 & 0xFFFFu] | ((uint32_t)kHalfToU8[w0 >> 16] << 8) | ((uint32_t)kHalfToU8[w1 & 0xFFFFu] << 16) | 0xFF000000u;
+	}
+}
+
+template <int EPI, int P, int NC = kNatRGBA8> struct Epilogue;
+template <int P, int NC> struct Epilogue<kEpiNone, P, NC> {
 	static constexpr int kRowDwords = P;		// dwords per 4-pixel row of the target
 	static DH void apply(const uint32_t (&d)[4 * P], uint32_t (&o)[4 * P]) {
 #pragma unroll
 		for (int k = 0; k < 4 * P; k++) o[k] = d[k];
 	}
 };
-template <> struct Epilogue<kEpiSwapRB8, 4> {
+template <> struct Epilogue<kEpiSwapRB8, 4, kNatRGBA8> {
 	static constexpr int kRowDwords = 4;
 	static DH void apply(const uint32_t (&d)[16], uint32_t (&o)[16]) {
 #pragma unroll
 		for (int k = 0; k < 16; k++) o[k] = perm(d[k], d[k], 0x03000102u);
 	}
 };
-template <> struct Epilogue<kEpiPackRGB8, 4> {
+// four RGBX8 pixels -> three dwords of packed RGB8
+DH void pack_rgb8_row(const uint32_t *px, uint32_t *o) {
+	o[0] = perm(px[1], px[0], 0x04020100u);	// R0 G0 B0 R1
+	o[1] = perm(px[2], px[1], 0x05040201u);	// G1 B1 R2 G2
+	o[2] = perm(px[3], px[2], 0x06050402u);	// B2 R3 G3 B3
+}
+template <> struct Epilogue<kEpiPackRGB8, 4, kNatRGBA8> {
 	static constexpr int kRowDwords = 3;
 	static DH void apply(const uint32_t (&d)[16], uint32_t (&o)[12]) {
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			o[3 * r + 0] = perm(d[4 * r + 1], d[4 * r + 0], 0x04020100u);	// R0 G0 B0 R1
-			o[3 * r + 1] = perm(d[4 * r + 2], d[4 * r + 1], 0x05040201u);	// G1 B1 R2 G2
-			o[3 * r + 2] = perm(d[4 * r + 3], d[4 * r + 2], 0x06050402u);	// B2 R3 G3 B3
-		}
+		for (int r = 0; r < 4; r++) pack_rgb8_row(d + 4 * r, o + 3 * r);
 	}
 };
-template <> struct Epilogue<kEpiSwapRB16, 8> {
+template <> struct Epilogue<kEpiSwapRB16, 8, kNatFloatRGBX16> {
 	static constexpr int kRowDwords = 8;
 	static DH void apply(const uint32_t (&d)[32], uint32_t (&o)[32]) {
 #pragma unroll
@@ -80,6 +118,33 @@ template <> struct Epilogue<kEpiSwapRB16, 8> {
 		}
 	}
 };
+template <int P, int NC> struct Epilogue<kEpiToRGBX8, P, NC> {
+	static constexpr int kRowDwords = 4;
+	static DH void apply(const uint32_t (&d)[4 * P], uint32_t (&o)[16]) {
+#pragma unroll
+		for (int k = 0; k < 16; k++) o[k] = pixel_as_rgbx8<NC>(d, k);
+	}
+};
+template <int P, int NC> struct Epilogue<kEpiToBGRX8, P, NC> {
+	static constexpr int kRowDwords = 4;
+	static DH void apply(const uint32_t (&d)[4 * P], uint32_t (&o)[16]) {
+#pragma unroll
+		for (int k = 0; k < 16; k++) { const uint32_t v = pixel_as_rgbx8<NC>(d, k); o[k] = perm(v, v, 0x03000102u); }
+	}
+};
+template <int P, int NC> struct Epilogue<kEpiToRGB8, P, NC> {
+	static constexpr int kRowDwords = 3;
+	static DH void apply(const uint32_t (&d)[4 * P], uint32_t (&o)[12]) {
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			uint32_t px[4];
+#pragma unroll
+			for (int x = 0; x < 4; x++) px[x] = pixel_as_rgbx8<NC>(d, 4 * r + x);
+			pack_rgb8_row(px, o + 3 * r);
+		}
+	}
+};
+template <class Dec, int EPI> using EpilogueOf = Epilogue<EPI, Dec::kPixelBytes, NativeOf<Dec>::value>;
 
 // one 4-pixel row of ROW dwords; non-temporal (streaming) or ordinary stores
 template <int ROW, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
@@ -186,7 +251,7 @@ template <class Dec> DH typename BlockWord<Dec::kBlockBytes>::type load_block(co
 // decode + zero-fill on failure + epilogue; returns ok
 template <class Dec, int EPI, bool CHECKED>
 DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint32_t mode_mask, uint32_t flags,
-		uint32_t (&o)[4 * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords]) {
+		uint32_t (&o)[4 * EpilogueOf<Dec, EPI>::kRowDwords]) {
 	constexpr int P = Dec::kPixelBytes;
 	uint32_t d[4 * P];
 #if defined(DETEXHIP_EXP_NOCOMPUTE)	// measurement build: memory traffic without the decode
@@ -196,16 +261,16 @@ DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint3
 #else
 	const bool ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
 #endif
-	if (!ok) {
+	EpilogueOf<Dec, EPI>::apply(d, o);
+	if (!ok) {	// texture.c:125-128: a failed block is zero-filled in the TARGET format (not "converted zeros": X / alpha stay 0)
 #pragma unroll
-		for (int k = 0; k < 4 * P; k++) d[k] = 0u;
+		for (int k = 0; k < 4 * EpilogueOf<Dec, EPI>::kRowDwords; k++) o[k] = 0u;
 	}
-	Epilogue<EPI, P>::apply(d, o);
 	return ok;
 }
 template <class Dec, int EPI, bool CHECKED>
 DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_t flags,
-		uint32_t (&o)[4 * Epilogue<EPI, Dec::kPixelBytes>::kRowDwords]) {
+		uint32_t (&o)[4 * EpilogueOf<Dec, EPI>::kRowDwords]) {
 	return decode_word<Dec, EPI, CHECKED>(load_block<Dec>(blocks, i), mode_mask, flags, o);
 }
 #if defined(DETEXHIP_EXP_NOSTORE)	// measurement build: the decode without its stores (the condition is practically never true)
@@ -222,7 +287,7 @@ template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
-	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
 	// the first block is requested before the table copy, so its HBM round trip overlaps the copy and the barrier
 	const uint32_t first = blockIdx.x * 256u + threadIdx.x;
@@ -303,7 +368,7 @@ template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
 		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
-	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
@@ -339,7 +404,7 @@ template <class Dec, int EPI, bool CHECKED>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
 		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
-	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;	// = 16-byte vectors per decoded block
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;	// = 16-byte vectors per decoded block
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
 	const uint32_t n_tiles = PersistentTiles<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear

@@ -27,7 +27,7 @@ struct LevelTable {
 
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status) {
-	constexpr int ROW = Epilogue<EPI, Dec::kPixelBytes>::kRowDwords;
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
 	// workgroup -> level: wave-uniform scalar search over <= 16 entries
 	uint32_t l = 0;

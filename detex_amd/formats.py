@@ -81,8 +81,12 @@ PIXEL_FORMAT_RGB8 = 0x220
 PIXEL_FORMAT_FLOAT_BGRX16 = 0x2729
 PIXEL_FORMAT_NAMES = {**_PIXEL_NAMES, 0x33C: "BGRA8", 0x328: "BGRX8", 0x220: "RGB8", 0x2729: "FLOAT_BGRX16"}
 
-# epilogue kinds (detex_amd/csrc/kernels.h, oracle orc_convert_pixels): 0 none, 1 swap R/B (8-bit),
-# 2 pack RGB8, 3 swap R/B (16-bit)
+# epilogue kinds (detex_amd/csrc/kernels.h, oracle orc_convert_pixels): 0 none, 1 swap R/B (8-bit), 2 pack RGB8,
+# 3 swap R/B (16-bit), 4/5/6 one-/two-component and half-float natives -> RGBX8 / BGRX8 / RGB8
+_SMALL_UNSIGNED = (PIXEL_FORMAT_R8, PIXEL_FORMAT_RG8, PIXEL_FORMAT_R16, PIXEL_FORMAT_RG16, PIXEL_FORMAT_FLOAT_RGBX16)
+_SMALL_SIGNED = (PIXEL_FORMAT_SIGNED_R16, PIXEL_FORMAT_SIGNED_RG16)
+
+
 def epilogue_kind(fmt, pixel_format):
     n = native_pixel_format(fmt)
     if pixel_format == n:
@@ -92,17 +96,27 @@ def epilogue_kind(fmt, pixel_format):
                 PIXEL_FORMAT_RGB8: 2}.get(pixel_format)
     if n == PIXEL_FORMAT_FLOAT_RGBX16 and pixel_format == PIXEL_FORMAT_FLOAT_BGRX16:
         return 3
+    if n in _SMALL_UNSIGNED or n in _SMALL_SIGNED:
+        if n in _SMALL_SIGNED and pixel_format == PIXEL_FORMAT_BGRA8:
+            return None                       # the reference finds no conversion path either (convert.c:885-1063)
+        return {PIXEL_FORMAT_RGBA8: 4, PIXEL_FORMAT_RGBX8: 4, PIXEL_FORMAT_BGRA8: 5, PIXEL_FORMAT_BGRX8: 5,
+                PIXEL_FORMAT_RGB8: 6}.get(pixel_format)
     return None
 
 
+ALL_TARGETS = (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8, PIXEL_FORMAT_BGRA8, PIXEL_FORMAT_BGRX8, PIXEL_FORMAT_RGB8,
+               PIXEL_FORMAT_FLOAT_BGRX16)
+
+
 def accepted_pixel_formats(fmt):
-    """Target pixel formats the block-decode path supports for ``fmt``: the native one, the
-    RGBX8<->RGBA8 no-op edge of the reference's conversion table (convert.c:768-769), and the
-    in-kernel epilogues: BGRA8/BGRX8/RGB8 for RGBA8-class formats, FLOAT_BGRX16
-    for unsigned BC6H."""
+    """Target pixel formats the block-decode path supports for ``fmt``: the native one, the RGBX8<->RGBA8 no-op
+    edge of the reference's conversion table (convert.c:768-769), and the in-kernel epilogues: every 8-bit RGB(A)
+    target the reference's callers request (BGRA8/BGRX8, RGB8, RGBA8/RGBX8) for every format the reference itself
+    can convert, FLOAT_BGRX16 for unsigned BC6H."""
     n = native_pixel_format(fmt)
-    if n in (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8):
-        return (PIXEL_FORMAT_RGBA8, PIXEL_FORMAT_RGBX8, PIXEL_FORMAT_BGRA8, PIXEL_FORMAT_BGRX8, PIXEL_FORMAT_RGB8)
-    if n == PIXEL_FORMAT_FLOAT_RGBX16:
-        return (n, PIXEL_FORMAT_FLOAT_BGRX16)
-    return (n,)
+    out = [n] + [pf for pf in ALL_TARGETS if pf != n and epilogue_kind(fmt, pf) is not None]
+    return tuple(out)
+
+
+def target_pixel_bytes(pixel_format):
+    return 1 + ((pixel_format & 0xF00) >> 8)

@@ -50,10 +50,13 @@ DETEXHIP_API const char *detexhipVersion(void);
  *                    and pitch_bytes are 16-byte aligned; any other geometry takes the clipped
  *                    per-pixel path (d_pixels, pitch_bytes aligned to the pixel size).
  *   pixel_format     native pixel format of texture_format; RGBA8/RGBX8 for either (the no-op
- *                    edge, convert.c:768-769); and, converted inside the kernel exactly as
- *                    detexConvertPixels would (convert.c:37-70,671-684): BGRA8, BGRX8, RGB8
- *                    for formats whose native target is RGBA8/RGBX8, FLOAT_BGRX16 for
- *                    BPTC_FLOAT.  Anything else is refused (rc != 0, nothing is written).
+ *                    edge, convert.c:768-769); and, converted inside the kernel with the exact
+ *                    result of the path detexConvertPixels takes (convert.c:885-1063): RGBA8,
+ *                    RGBX8, BGRA8, BGRX8, RGB8 for every format the reference itself can convert
+ *                    to them (all but BPTC_SIGNED_FLOAT; the signed 16-bit formats have no path
+ *                    to BGRA8), FLOAT_BGRX16 for BPTC_FLOAT.  Anything else is refused (rc != 0,
+ *                    nothing is written).  The first BPTC_FLOAT -> 8-bit call on a device uploads
+ *                    a 64 KiB table synchronously (not capturable into a hipGraph; later calls are).
  *   d_status         optional device uint32_t: set to 1 by the kernel if any block was invalid
  *                    (those blocks are zero-filled, decoding continues: texture.c:125-128).
  *                    The caller zeroes it beforehand and reads it after synchronising;
@@ -144,6 +147,11 @@ DETEXHIP_API int detexhipModeHistogramDevice(uint32_t texture_format, const void
 	uint32_t *d_hist, void *stream);
 DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,
 	uint32_t histogram[16]);
+
+/* The 8-bit value the FLOAT_RGBX16 -> RGBA8/RGBX8/BGRA8/BGRX8/RGB8 epilogues write for one half-float component:
+ * the reference's FLOAT_RGBX16 -> RGBX16 -> RGBX8 chain (half-float.c:304-312, convert.c:299-313).  Host function
+ * (the kernels use a device table built from it); exposed so the table can be checked without a GPU. */
+DETEXHIP_API uint8_t detexhipHalfFloatToUNorm8(uint16_t half_bits);
 
 /* Kernel-variant selection for A/B measurements.  The product library has ONE kernel per
  * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab,

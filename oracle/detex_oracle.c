@@ -784,19 +784,78 @@ uint64_t orc_fnv1a64(const uint8_t *p, size_t n) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * The pixel-format conversions the GPU path offers as in-kernel epilogues.
- * Semantics of the reference's converters: R<->B swap keeps the 4th component
- * (convert.c:37-52 for 8-bit, :54-70 for 16-bit), RGBX8 -> RGB8 drops it (convert.c:671-684).
+ * The pixel-format conversions the GPU path offers as in-kernel epilogues (SURVEY.md 8f-2 and the
+ * targets the reference's callers request, validate.c:204-209 / detex-view.c:182 / detex-convert.c:283-284).
+ * Each is the composition detexMatchConversion (convert.c:885-1063) picks for that (source, target):
+ *   kind 1  R<->B swap of 8-bit RGBA, 4th component kept (convert.c:37-52)
+ *   kind 2  RGBX8 -> RGB8 (convert.c:671-684)
+ *   kind 3  R<->B swap of 16-bit RGBX (convert.c:54-70)
+ *   kind 4/5/6  native R8 | RG8 | R16 | RG16 | SIGNED_R16 | SIGNED_RG16 | FLOAT_RGBX16 -> RGBX8 | BGRX8 | RGB8:
+ *       signed 16 -> unsigned 16 by + 32768 (convert.c:158-181); 16 -> 8 by (x + 127) * 255 / 65535
+ *       (convert.c:258-281, 299-313); half -> 16 by lrintf(clamp01(f) * 65535.0f + 0.5f) with FE_DOWNWARD
+ *       (half-float.c:304-312); 1/2 components -> RGBX8 with 0 for the missing ones and 0xFF for X
+ *       (convert.c:219-243); then kind 1 / kind 2 as above.
+ * native_pf is the decoder's pixel format (detex.h:83-379).  Pinned to the compiled reference component by
+ * component (all 65536 values) in tests/test_oracle_pin.py.
  * ---------------------------------------------------------------------------------------- */
-long orc_convert_pixels(int kind, const uint8_t *in, long n_pixels, uint8_t *out) {
+#include <fenv.h>
+#include <math.h>
+static float orc_half_to_float(uint16_t h) {	/* exact (what half-float.c's table holds) */
+	const uint32_t sign = h >> 15, exponent = (h >> 10) & 31u, mantissa = h & 1023u;
+	float f;
+	if (exponent == 31u) f = mantissa ? NAN : INFINITY;
+	else if (exponent == 0u) f = ldexpf((float)mantissa, -24);
+	else f = ldexpf((float)(mantissa + 1024u), (int)exponent - 25);
+	return sign ? -f : f;
+}
+static uint32_t orc_16_to_8(uint32_t x) { return (x + 127u) * 255u / 65535u; }
+static uint32_t orc_half_to_16(uint16_t h) {
+	volatile float f = orc_half_to_float(h);	/* volatile: the arithmetic below must run under the rounding mode set here */
+	const int saved = fegetround();
+	fesetround(FE_DOWNWARD);
+	/* NaN: the reference build (gcc -Ofast: comparisons assume no NaN) yields 1.0 for every NaN pattern -- pinned to it
+	 * over all 65536 patterns; BC6H itself never decodes to Inf or NaN (largest half 0x7BFF) */
+	volatile float c = f != f ? 1.0f : (f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f));
+	volatile float t = c * 65535.0f;
+	t = t + 0.5f;
+	const long u = lrintf(t);
+	fesetround(saved);
+	return (uint32_t)u & 0xFFFFu;
+}
+/* pixel i of `in` (native format) as R, G, B bytes */
+static int orc_native_rgb(uint32_t native_pf, const uint8_t *in, long i, uint8_t rgb[3]) {
+	uint16_t v[4];
+	rgb[0] = rgb[1] = rgb[2] = 0;
+	switch (native_pf) {
+	case 0x0000: rgb[0] = in[i]; return 0;						/* R8 */
+	case 0x0110: rgb[0] = in[2 * i]; rgb[1] = in[2 * i + 1]; return 0;		/* RG8 */
+	case 0x0101: memcpy(v, in + 2 * i, 2); rgb[0] = (uint8_t)orc_16_to_8(v[0]); return 0;	/* R16 */
+	case 0x1101: memcpy(v, in + 2 * i, 2); rgb[0] = (uint8_t)orc_16_to_8((uint16_t)(v[0] + 32768u)); return 0;	/* SIGNED_R16 */
+	case 0x0311: memcpy(v, in + 4 * i, 4); rgb[0] = (uint8_t)orc_16_to_8(v[0]); rgb[1] = (uint8_t)orc_16_to_8(v[1]); return 0;	/* RG16 */
+	case 0x1311: memcpy(v, in + 4 * i, 4); rgb[0] = (uint8_t)orc_16_to_8((uint16_t)(v[0] + 32768u));
+		rgb[1] = (uint8_t)orc_16_to_8((uint16_t)(v[1] + 32768u)); return 0;		/* SIGNED_RG16 */
+	case 0x2721: memcpy(v, in + 8 * i, 8);							/* FLOAT_RGBX16 */
+		for (int c = 0; c < 3; c++) rgb[c] = (uint8_t)orc_16_to_8(orc_half_to_16(v[c]));
+		return 0;
+	default: return -1;
+	}
+}
+long orc_convert_pixels(uint32_t native_pf, int kind, const uint8_t *in, long n_pixels, uint8_t *out) {
 	for (long i = 0; i < n_pixels; i++) {
+		uint8_t rgb[3];
 		switch (kind) {
 		case 1: out[4 * i] = in[4 * i + 2]; out[4 * i + 1] = in[4 * i + 1]; out[4 * i + 2] = in[4 * i]; out[4 * i + 3] = in[4 * i + 3]; break;
 		case 2: out[3 * i] = in[4 * i]; out[3 * i + 1] = in[4 * i + 1]; out[3 * i + 2] = in[4 * i + 2]; break;
 		case 3: memcpy(out + 8 * i, in + 8 * i + 4, 2); memcpy(out + 8 * i + 2, in + 8 * i + 2, 2);
 			memcpy(out + 8 * i + 4, in + 8 * i, 2); memcpy(out + 8 * i + 6, in + 8 * i + 6, 2); break;
+		case 4: if (orc_native_rgb(native_pf, in, i, rgb)) return -1;
+			out[4 * i] = rgb[0]; out[4 * i + 1] = rgb[1]; out[4 * i + 2] = rgb[2]; out[4 * i + 3] = 0xFF; break;
+		case 5: if (orc_native_rgb(native_pf, in, i, rgb)) return -1;
+			out[4 * i] = rgb[2]; out[4 * i + 1] = rgb[1]; out[4 * i + 2] = rgb[0]; out[4 * i + 3] = 0xFF; break;
+		case 6: if (orc_native_rgb(native_pf, in, i, rgb)) return -1;
+			out[3 * i] = rgb[0]; out[3 * i + 1] = rgb[1]; out[3 * i + 2] = rgb[2]; break;
 		default: return -1;
 		}
 	}
-	return n_pixels * (kind == 2 ? 3 : (kind == 3 ? 8 : 4));
+	return n_pixels * ((kind == 2 || kind == 6) ? 3 : (kind == 3 ? 8 : 4));
 }

@@ -58,7 +58,7 @@ int orc_block_mode(int fmt, const uint8_t *bitstring);
 uint64_t orc_fnv1a64(const uint8_t *p, size_t n);
 /* pixel conversions offered as GPU epilogues: kind 1 = swap R/B of 32-bit pixels, 2 = RGBX8 -> RGB8,
  * 3 = swap R/B of 64-bit (4 x 16) pixels; returns bytes written (convert.c:37-70, 671-684) */
-long orc_convert_pixels(int kind, const uint8_t *in, long n_pixels, uint8_t *out);
+long orc_convert_pixels(uint32_t native_pixel_format, int kind, const uint8_t *in, long n_pixels, uint8_t *out);
 void orc_block_modes(int fmt, const uint8_t *data, long n_blocks, int32_t *modes_out);
 void orc_decode_blocks(int fmt, const uint8_t *data, long n_blocks, uint32_t mode_mask, uint32_t flags,
 	uint8_t *pixel_buffer, uint8_t *ok_out);

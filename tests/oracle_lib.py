@@ -63,19 +63,44 @@ class Oracle:
         if kind == 0:
             return native_pixels
         n = native_pixels.size // fmt.pixel_bytes
-        out = np.zeros(n * (3 if kind == 2 else fmt.pixel_bytes), np.uint8)
+        out = np.zeros(n * F.target_pixel_bytes(pixel_format), np.uint8)
         self.lib.orc_convert_pixels.restype = ctypes.c_long
-        self.lib.orc_convert_pixels.argtypes = [ctypes.c_int, _u8p, ctypes.c_long, _u8p]
-        assert self.lib.orc_convert_pixels(kind, _ptr(native_pixels), n, _ptr(out)) == out.size
+        self.lib.orc_convert_pixels.argtypes = [ctypes.c_uint32, ctypes.c_int, _u8p, ctypes.c_long, _u8p]
+        assert self.lib.orc_convert_pixels(F.native_pixel_format(fmt), kind, _ptr(native_pixels), n, _ptr(out)) == out.size
         return out
 
+    def _zero_failed_blocks(self, fmt, data, converted, tpx, wb, hb, width=None, height=None):
+        """texture.c:125-128: a block whose decode fails is zero-filled in the TARGET format (the conversion never runs
+        for it), so its pixels are zero bytes -- not converted zeros (X / alpha = 0xFF)"""
+        okb, _ = self.blocks(fmt, np.ascontiguousarray(data, np.uint8)[:wb * hb * fmt.block_bytes].reshape(-1, fmt.block_bytes))
+        bad = np.flatnonzero(~okb)
+        if bad.size == 0:
+            return converted
+        if width is None:                                   # block-major layout
+            v = converted.reshape(-1, 16 * tpx)
+            v[bad] = 0
+            return converted
+        img = converted.reshape(height, width * tpx)
+        for b in bad:
+            by, bx = divmod(int(b), wb)
+            img[by * 4:by * 4 + 4, bx * 4 * tpx:(bx * 4 + 4) * tpx] = 0
+        return converted
+
     def linear_to(self, fmt, data, width, height, pixel_format):
+        from detex_amd import formats as F
         ok, out = self.linear(fmt, data, width, height)
-        return ok, self.convert(fmt, out, pixel_format)
+        conv = self.convert(fmt, out, pixel_format)
+        if not ok and F.epilogue_kind(fmt, pixel_format) >= 4:
+            conv = self._zero_failed_blocks(fmt, data, conv.copy(), F.target_pixel_bytes(pixel_format), (width + 3) // 4, (height + 3) // 4, width, height)
+        return ok, conv
 
     def tiled_to(self, fmt, data, wb, hb, pixel_format):
+        from detex_amd import formats as F
         ok, out = self.tiled(fmt, data, wb, hb)
-        return ok, self.convert(fmt, out, pixel_format)
+        conv = self.convert(fmt, out, pixel_format)
+        if not ok and F.epilogue_kind(fmt, pixel_format) >= 4:
+            conv = self._zero_failed_blocks(fmt, data, conv.copy(), F.target_pixel_bytes(pixel_format), wb, hb)
+        return ok, conv
 
     def modes(self, fmt, data):
         data = np.ascontiguousarray(data, dtype=np.uint8)

@@ -29,7 +29,7 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = binding.load()
     declared = _declared_symbols()
-    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 5) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device, release, host aliases), data tables
+    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 6) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device, release, host aliases, half table), data tables
     out = subprocess.check_output(["nm", "-D", "--defined-only", binding.LIB_PATH], text=True)
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert declared <= exported, sorted(declared - exported)
@@ -142,3 +142,17 @@ int main(void) {
         subprocess.check_call(["gcc", "-I" + inc, str(probe), "-o", str(e)])
         vals[inc] = subprocess.check_output([str(e)], text=True)
     assert vals["/root/reference"] == vals[os.path.join(ROOT, "include")]
+
+
+def test_half_float_table_matches_the_oracle_chain(oracle):
+    """all 65536 half patterns: the host function the device table is built from == the restated FLOAT_RGBX16 ->
+    RGBX16 -> RGBX8 chain (itself pinned to the compiled reference in tests/test_oracle_pin.py)"""
+    lib = binding.load()
+    lib.detexhipHalfFloatToUNorm8.restype = ctypes.c_uint8
+    lib.detexhipHalfFloatToUNorm8.argtypes = [ctypes.c_uint16]
+    got = np.array([lib.detexhipHalfFloatToUNorm8(h) for h in range(65536)], np.uint8)
+    fmt = F.BY_NAME["BPTC_FLOAT"]
+    src = np.zeros((65536, 4), np.uint16)
+    src[:, 0] = np.arange(65536)
+    want = oracle.convert(fmt, src.view(np.uint8).reshape(-1), F.PIXEL_FORMAT_RGBX8).reshape(-1, 4)[:, 0]
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]

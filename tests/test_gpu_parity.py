@@ -257,12 +257,10 @@ def test_full_size_digest(name, torch_cuda, golden_json):
     fmt = F.BY_NAME[name]
     dg = golden_json("digests_8192.json")
     W, H = dg["width"], dg["height"]
-    kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT") else [])
-    for kind in kinds:
+    kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT") else []) + (["C"] if fmt.fixture else [])
+    for kind in kinds:                              # U uniform random, M modes equiprobable, C the bundled fixture tiled
         g = dg["streams"]["%s/%s" % (name, kind)]   # native target; epilogue targets: test_full_size_digest_epilogue_targets
-        data = ol.stream_u(fmt, (W // 4) * (H // 4))
-        if kind == "M":
-            data = streams.stream_m(fmt, data)
+        data = streams.make_stream(kind, fmt, W // 4, H // 4)
         assert sha(data) == g["in_sha256"], "stream generator drifted"
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
         out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
@@ -274,31 +272,33 @@ def test_full_size_digest(name, torch_cuda, golden_json):
 
 
 # ---- size-independent properties at full size -----------------------------------------------------
-def test_properties_full_size(torch_cuda):
-    """(a) row-band sharding: decoding block-row bands separately into the same image is
-    identical to one whole-image decode (the multi-GPU decomposition of SURVEY 8e);
+@pytest.mark.parametrize("name,W,H", [("BC1", 4096, 4096), ("BPTC", 4096, 4096), ("BPTC_FLOAT", 4096, 4096), ("BPTC_SIGNED_FLOAT", 4096, 2048),
+                                      ("RGTC1", 4096, 4096), ("EAC_R11", 4096, 2048), ("BPTC_FLOAT", 8000, 2000), ("BC3", 8000, 2000),
+                                      ("RGTC2", 8000, 1000)])
+def test_properties_full_size(name, W, H, torch_cuda):
+    """(a) row-band sharding: decoding block-row bands separately into the same image is identical to one whole-image
+    decode (the multi-GPU decomposition of SURVEY 8e) -- for 1-, 2-, 4- and 8-byte pixels (the 64-bit ones leave through
+    the per-wave LDS transpose) and for widths that are not powers of two (waves straddle block rows);
     (b) linear and tiled layouts hold the same texels; (c) decode is idempotent."""
     from detex_amd import binding
     torch = torch_cuda
-    for name in ("BC1", "BPTC"):
-        fmt = F.BY_NAME[name]
-        W = H = 4096
-        wb, hb = W // 4, H // 4
-        d_blocks = _dev(torch, ol.stream_u(fmt, wb * hb, seed=99))
-        whole = binding.decompress_linear_device(fmt, d_blocks, W, H)
-        again = binding.decompress_linear_device(fmt, d_blocks, W, H)
-        banded = torch.zeros_like(whole)
-        px = fmt.pixel_bytes
-        for g in range(8):
-            r0, r1 = g * hb // 8, (g + 1) * hb // 8
-            binding.decompress_linear_device(fmt, d_blocks[r0 * wb * fmt.block_bytes:], W, (r1 - r0) * 4,
-                                             out=banded[r0 * 4 * W * px:])
-        tiled = binding.decompress_tiled_device(fmt, d_blocks, wb, hb)
-        torch.cuda.synchronize()
-        assert torch.equal(whole, again)
-        assert torch.equal(whole, banded)
-        t = tiled.view(hb, wb, 4, 4 * px).permute(0, 2, 1, 3).reshape(-1)
-        assert torch.equal(t, whole)
+    fmt = F.BY_NAME[name]
+    wb, hb = W // 4, H // 4
+    d_blocks = _dev(torch, ol.stream_u(fmt, wb * hb, seed=99))
+    whole = binding.decompress_linear_device(fmt, d_blocks, W, H)
+    again = binding.decompress_linear_device(fmt, d_blocks, W, H)
+    banded = torch.zeros_like(whole)
+    px = fmt.pixel_bytes
+    for g in range(8):
+        r0, r1 = g * hb // 8, (g + 1) * hb // 8
+        binding.decompress_linear_device(fmt, d_blocks[r0 * wb * fmt.block_bytes:], W, (r1 - r0) * 4,
+                                         out=banded[r0 * 4 * W * px:])
+    tiled = binding.decompress_tiled_device(fmt, d_blocks, wb, hb)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, again)
+    assert torch.equal(whole, banded)
+    t = tiled.view(hb, wb, 4, 4 * px).permute(0, 2, 1, 3).reshape(-1)
+    assert torch.equal(t, whole)
 
 
 def test_unsupported_targets_fail_loudly(hiplib):
@@ -327,12 +327,32 @@ def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), want_l)
 
 
-@pytest.mark.parametrize("name,W,H", [("BC1", 32768, 32768), ("BPTC_FLOAT", 32768, 4096)])
-def test_maximum_size_textures(name, W, H, torch_cuda, oracle):
-    """the largest configurations of BASELINE.json (32768-wide; 4 GiB / 1 GiB of pixels): 64-bit addressing and the
-    block index arithmetic, checked bit-exact at the top, middle and bottom block rows"""
+@pytest.mark.parametrize("name,W,H", [("BC1", 32768, 8192), ("BPTC_FLOAT", 32768, 4096)])
+def test_sharded_config_bands_whole_digest(name, W, H, torch_cuda, golden_json):
+    """one GPU's band of the sharded 32768^2 configurations (BASELINE configs[4] / north_star: BC1 over 4 GPUs, BC6H over
+    8): sha256 of the WHOLE band (1 GiB of pixels) against the compiled reference's (tools/make_goldens.py bands)"""
     from detex_amd import binding
     torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    g = golden_json("digests_8192.json")["bands"]["%s/%dx%d" % (name, W, H)]
+    data = ol.stream_u(fmt, (W // 4) * (H // 4))
+    assert sha(data) == g["in_sha256"]
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+    torch.cuda.synchronize()
+    assert out.numel() == g["bytes"] and bool(status.item() == 0) == g["ok"]
+    assert sha(out.cpu().numpy()) == g["sha256"]
+    del out
+    torch.cuda.empty_cache()
+
+
+def test_maximum_size_texture(torch_cuda, oracle):
+    """the largest single texture the API takes (32768 x 32768 BC1: 4 GiB of pixels in one launch): 64-bit addressing and
+    the block index arithmetic, checked bit-exact at the top, middle and bottom block rows (whole bands of this width
+    are digested in test_sharded_config_bands_whole_digest)"""
+    from detex_amd import binding
+    torch = torch_cuda
+    name, W, H = "BC1", 32768, 32768
     fmt = F.BY_NAME[name]
     wb, hb = W // 4, H // 4
     data = np.random.default_rng(5).integers(0, 256, size=wb * hb * fmt.block_bytes, dtype=np.uint8)

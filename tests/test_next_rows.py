@@ -173,7 +173,9 @@ def torch_cuda():
 
 @pytest.mark.gpu
 def test_reference_call_sequence_file_to_pixels(hiplib, golden_json):
-    """validate.c:135,208 end to end against libdetexhip: detexLoadKTXFile -> detexDecompressTextureLinear(BGRA8|native)"""
+    """validate.c:135,199-209 end to end against libdetexhip for ALL 17 bundled fixtures: detexLoadKTXFile ->
+    detexDecompressTextureLinear(BGRA8 if detexFormatHasAlpha(format) else BGRX8) -- the call the reference's own
+    validation program makes for every format, including the one-/two-component, signed and half-float ones"""
     ours = _loader(binding.LIB_PATH)
     want = golden_json("fixtures.json")
     for f in F.FORMATS:
@@ -181,8 +183,9 @@ def test_reference_call_sequence_file_to_pixels(hiplib, golden_json):
             continue
         tp = TexP()
         assert ours.detexLoadKTXFile(os.path.join(GOLDEN, f.fixture).encode(), ctypes.byref(tp))
-        pf = F.PIXEL_FORMAT_BGRA8 if F.PIXEL_FORMAT_BGRA8 in F.accepted_pixel_formats(f) else F.native_pixel_format(f)
-        out = np.zeros(64 * 64 * (1 + ((pf & 0xF00) >> 8)), np.uint8)
+        pf = F.PIXEL_FORMAT_BGRA8 if (f.texture_format & 0x4) else F.PIXEL_FORMAT_BGRX8       # detexFormatHasAlpha, detex.h:89,907-909
+        assert pf in F.accepted_pixel_formats(f), f.name
+        out = np.zeros(64 * 64 * 4, np.uint8)
         ok = hiplib.lib.detexDecompressTextureLinear(tp, ol._ptr(out), pf)
         g = want[f.name]["0x%04X" % pf]
         assert bool(ok) == g["ok"] and sha(out) == g["sha256"], f.name

@@ -10,8 +10,10 @@ What it writes is data only -- inputs and the reference's outputs:
   tests/golden/forced_vectors.npz   mode-forced blocks (tests/streams.py) + reference output + ok flag
   tests/golden/maskflags.json       per (format, mode_mask, flags): ok bitmap + sha256 of outputs
   tests/golden/clip.npz             clipped (width/height not multiples of 4) linear decodes
-  tests/golden/digests_8192.json    sha256 + FNV-1a-64 of the reference output on the seeded
-                                    8192x8192 streams U (all formats) and M (BPTC, BPTC_FLOAT)
+  tests/golden/digests_8192.json    sha256 (+ FNV-1a-64) of the reference output on the 8192x8192 streams U (all formats),
+                                    M (BPTC, BPTC_FLOAT) and C (every format with a fixture), on converted targets, and on
+                                    whole 32768-wide bands of the sharded configs
+usage: python tools/make_goldens.py [fixtures] [vectors] [digests] [digests_c] [digests_pf] [bands]   (default: all)
 """
 import ctypes, hashlib, json, os, shutil, sys, time
 import numpy as np
@@ -25,12 +27,87 @@ REF_DIR = "/root/reference"
 G = os.path.join(ROOT, "tests", "golden")
 sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
+def ref_linear_mt(ref, f, data, W, H, pf=None, threads=None):
+    """detexDecompressTextureLinear of the compiled reference over row bands on a thread pool (all reference state is
+    __thread; ctypes releases the GIL).  Returns (ok, pixels)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or min(16, os.cpu_count() or 1)
+    pf = (f.texture_format & 0xFFFF) if pf is None else pf
+    px = 1 + ((pf & 0xF00) >> 8)
+    wb, hb = W // 4, H // 4
+    out = np.empty(W * H * px, np.uint8)
+    data = np.ascontiguousarray(data)
+
+    def band(g):
+        r0, r1 = g * hb // threads, (g + 1) * hb // threads
+        if r1 <= r0:
+            return True
+        tex = ol.DetexTexture(f.texture_format, ol._ptr(data[r0 * wb * f.block_bytes:]), W, (r1 - r0) * 4, wb, r1 - r0)
+        return bool(ref.lib.detexDecompressTextureLinear(ctypes.byref(tex), ol._ptr(out[r0 * 4 * W * px:]), pf))
+    with ThreadPoolExecutor(threads) as pool:
+        oks = list(pool.map(band, range(threads)))
+    return all(oks), out
+
+
 def main():
+    sections = set(sys.argv[1:]) or {"fixtures", "vectors", "digests", "digests_c", "digests_pf", "bands"}
     os.makedirs(G, exist_ok=True)
     ref = ol.load_ref(); orc = ol.Oracle()
     orc.lib.orc_fnv1a64.restype = ctypes.c_uint64
     orc.lib.orc_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    # (i) fixtures
+    if "fixtures" in sections:
+        make_fixtures(ref)
+    if "vectors" in sections:
+        make_vectors(ref)
+    dpath = os.path.join(G, "digests_8192.json")
+    W = H = 8192
+    if "digests" in sections or not os.path.exists(dpath):
+        dg = {"generator": "splitmix64, seed 0xD37E5000+k (tests/oracle_lib.py stream_u)", "width": 8192, "height": 8192,
+              "reference_build": open(os.path.join(ROOT, "oracle/_ref/BUILD_INFO.txt")).read().strip(), "streams": {}}
+        for f in F.FORMATS:
+            for kind in ("U", "M"):
+                if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT"): continue
+                data = ol.stream_u(f, (W // 4) * (H // 4))
+                if kind == "M": data = streams.stream_m(f, data)
+                t = time.time(); ok, out = ref_linear_mt(ref, f, data, W, H); dt = time.time() - t
+                fnv = orc.lib.orc_fnv1a64(out.ctypes.data, out.size)
+                dg["streams"]["%s/%s" % (f.name, kind)] = {"ok": ok, "sha256": sha(out), "fnv1a64": "%016x" % fnv, "in_sha256": sha(data)}
+                print(f.name, kind, ok, "%016x" % fnv, "%.2fs" % dt, flush=True)
+    else:
+        dg = json.load(open(dpath))
+    if "digests_c" in sections:
+        # stream C (SURVEY.md 8d): the bundled 64x64 fixture tiled over 8192^2 (tests/streams.py stream_c)
+        for f in F.FORMATS:
+            data = streams.stream_c(f, W // 4, H // 4)
+            if data is None: continue
+            ok, out = ref_linear_mt(ref, f, data, W, H)
+            dg["streams"]["%s/C" % f.name] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data)}
+            print(f.name, "C", ok, flush=True)
+    if "digests_pf" in sections:
+        # converted targets at full size (in-kernel epilogues)
+        for key in [k for k in dg["streams"] if "/pf" in k]:
+            del dg["streams"][key]
+        for name, pf in (("BC1", F.PIXEL_FORMAT_BGRA8), ("BC1", F.PIXEL_FORMAT_RGB8), ("BC3", F.PIXEL_FORMAT_RGB8),
+                         ("BPTC_FLOAT", F.PIXEL_FORMAT_FLOAT_BGRX16), ("BPTC_FLOAT", F.PIXEL_FORMAT_BGRX8), ("RGTC1", F.PIXEL_FORMAT_BGRX8),
+                         ("EAC_RG11", F.PIXEL_FORMAT_RGB8), ("SIGNED_RGTC2", F.PIXEL_FORMAT_RGBA8), ("EAC_SIGNED_R11", F.PIXEL_FORMAT_BGRX8)):
+            f = F.BY_NAME[name]
+            data = ol.stream_u(f, (W // 4) * (H // 4))
+            ok, out = ref_linear_mt(ref, f, data, W, H, pf)
+            dg["streams"]["%s/U/pf%04X" % (name, pf)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
+            print(name, "U pf%04X" % pf, ok, flush=True)
+    if "bands" in sections:
+        # one GPU's band of the sharded 32768^2 configs (BASELINE configs[4], north_star): sha256 of the WHOLE band
+        dg.setdefault("bands", {})
+        for name, bw, bh in (("BC1", 32768, 8192), ("BPTC_FLOAT", 32768, 4096)):
+            f = F.BY_NAME[name]
+            data = ol.stream_u(f, (bw // 4) * (bh // 4))
+            t = time.time(); ok, out = ref_linear_mt(ref, f, data, bw, bh); dt = time.time() - t
+            dg["bands"]["%s/%dx%d" % (name, bw, bh)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
+            print(name, bw, bh, ok, "%.1fs" % dt, flush=True)
+    json.dump(dg, open(dpath, "w"), indent=1, sort_keys=True)
+
+
+def make_fixtures(ref):
     fx = {}
     for f in F.FORMATS:
         if not f.fixture: continue
@@ -41,9 +118,16 @@ def main():
         for pf in F.accepted_pixel_formats(f):
             ok, out = ref.linear(f, k["data"], 64, 64, pixel_format=pf)
             ent["0x%04X" % pf] = {"ok": ok, "sha256": sha(out), "bytes": int(out.size)}
+        # an 8-bit RGB(A) target this library refuses must be one the reference cannot reach either
+        for pf in F.ALL_TARGETS[:5]:
+            if pf not in F.accepted_pixel_formats(f):
+                ok, _ = ref.linear(f, k["data"], 64, 64, pixel_format=pf)
+                assert not ok, (f.name, hex(pf), "the reference converts this; the library should offer it")
         fx[f.name] = ent
     json.dump(fx, open(os.path.join(G, "fixtures.json"), "w"), indent=1, sort_keys=True)
-    # (ii) forced vectors, (iii) mask/flag matrix, clip cases
+
+
+def make_vectors(ref):
     vec, clip, mf = {}, {}, {}
     for f in F.FORMATS:
         blocks, labels = streams.forced_stream(f)
@@ -80,29 +164,7 @@ def main():
     np.savez_compressed(os.path.join(G, "forced_vectors.npz"), **vec)
     np.savez_compressed(os.path.join(G, "clip.npz"), **clip)
     json.dump(mf, open(os.path.join(G, "maskflags.json"), "w"), indent=0, sort_keys=True)
-    # (iv) full-size digests
-    dg = {"generator": "splitmix64, seed 0xD37E5000+k (tests/oracle_lib.py stream_u)", "width": 8192, "height": 8192,
-          "reference_build": open(os.path.join(ROOT, "oracle/_ref/BUILD_INFO.txt")).read().strip(), "streams": {}}
-    W = H = 8192
-    for f in F.FORMATS:
-        for kind in ("U", "M"):
-            if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT"): continue
-            data = ol.stream_u(f, (W // 4) * (H // 4))
-            if kind == "M": data = streams.stream_m(f, data)
-            t = time.time(); ok, out = ref.linear(f, data, W, H); dt = time.time() - t
-            fnv = orc.lib.orc_fnv1a64(out.ctypes.data, out.size)
-            dg["streams"]["%s/%s" % (f.name, kind)] = {"ok": ok, "sha256": sha(out), "fnv1a64": "%016x" % fnv,
-                "in_sha256": sha(data), "ref_seconds_1thread": round(dt, 3)}
-            print(f.name, kind, ok, "%016x" % fnv, "%.2fs" % dt, flush=True)
-    # converted targets at full size (in-kernel epilogues)
-    for name, pf in (("BC1", F.PIXEL_FORMAT_BGRA8), ("BC1", F.PIXEL_FORMAT_RGB8), ("BC3", F.PIXEL_FORMAT_RGB8),
-                     ("BPTC_FLOAT", F.PIXEL_FORMAT_FLOAT_BGRX16)):
-        f = F.BY_NAME[name]
-        data = ol.stream_u(f, (W // 4) * (H // 4))
-        ok, out = ref.linear(f, data, W, H, pixel_format=pf)
-        dg["streams"]["%s/U/pf%04X" % (name, pf)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
-        print(name, "U pf%04X" % pf, ok, flush=True)
-    json.dump(dg, open(os.path.join(G, "digests_8192.json"), "w"), indent=1, sort_keys=True)
+
 
 if __name__ == "__main__":
     main()
