@@ -211,10 +211,9 @@ template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
 template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks, size_t n, uint32_t *hist, hipStream_t stream) {
 	hipError_t e = hipMemsetAsync(hist, 0, 16 * sizeof(uint32_t), stream);
 	if (e != hipSuccess || n == 0) return e;
-	// persistent grid: every workgroup ends with up to 16 global atomics on the same cache line, which serialise
-	// in L2 (2048 workgroups: ~20 us of atomics for a 13 us read) -- two workgroups per CU keep the loads in
-	// flight (four per lane per trip) with a quarter of the atomics
-	const unsigned grid = (unsigned)((n + 255u) / 256u < 512u ? (n + 255u) / 256u : 512u);
+	// one workgroup per CU, eight loads in flight per lane (8 MiB on the wire for 16-byte blocks); every further
+	// workgroup adds serialised global atomics at the end (kernels_extra.h)
+	const unsigned grid = (unsigned)((n + 255u) / 256u < 256u ? (n + 255u) / 256u : 256u);
 	hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS>), dim3(grid), dim3(256), 0, stream, static_cast<const uint32_t *>(blocks),
 		(uint32_t)n, hist);
 	return hipGetLastError();
