@@ -17,6 +17,7 @@ __constant__ uint16_t kPartition1Bit[64] = { DETEXHIP_P2_WORDS };
 // the same constants for compile-time table derivation (decode_bptc.h builds its LDS tables from them)
 constexpr uint32_t kPartition2BitCx[128] = { DETEXHIP_P2X_WORDS, DETEXHIP_P3_WORDS };
 constexpr uint16_t kAnchorWordsCx[64] = { DETEXHIP_ANCHOR_WORDS };
+constexpr uint16_t kPartition1BitCx[64] = { DETEXHIP_P2_WORDS };
 
 // packed 2 x u16 arithmetic in one VGPR (v_pk_mad_u16 / v_pk_sub_u16): lanes wrap mod 2^16
 typedef uint16_t pk16 __attribute__((vector_size(4)));

@@ -160,19 +160,88 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 	bc6h_derive(7).w, bc6h_derive(8).w, bc6h_derive(9).w, bc6h_derive(10).w, bc6h_derive(11).w, bc6h_derive(12).w, bc6h_derive(13).w,
 };
 
-// workgroup copy of the mode words in LDS (dev_common.h: prepare_tables); the partition / anchor words come
-// from the BPTC tables (bptc_common.h)
+// ---- partition / index-stream table -----------------------------------------------------------------------
+// One entry per two-subset partition (5-bit partition number) plus entry 32 for the one-subset modes, everything the
+// texel loop needs that depends only on (partition, subset count), derived at compile time:
+//   pmask12   one-bit subset number per texel, shifted to bit 12 (texel i's bit at 12 + i): a texel's LDS row address
+//             is one shift and one v_bitop3_b32
+//   route     lo | hi << 5 | hshift << 10: where the second subset's anchor is missing its top index bit -- position of
+//             the zero bit to insert into the first (texels 0-7) or the second (8-15) 32-bit index window, 31 = none
+//             (windows of 3-bit indices are 24 bits wide; one-subset blocks shift a zero word: `ones`); hshift = where
+//             the second window starts in the block's last dword (decompress-bptc-float.c:535-564)
+//   himask0   texel 0's own missing bit (bit 2 or 3 of the first window)
+//   wmul/wadd/imask/ibits   index width, mask and the closed-form weight constants (bptc_common.h)
+struct alignas(16) Bc6hPartEntry { uint32_t pmask12, route, himask0, ones, wmul, wadd, imask, ibits; };
+struct Bc6hPartTable { Bc6hPartEntry e[33]; };
+constexpr Bc6hPartTable bc6h_part_table() {
+	Bc6hPartTable t = {};
+	for (uint32_t p = 0; p < 32u; p++) {
+		const uint32_t a = kAnchorWordsCx[p] & 15u;
+		const uint32_t lo = a < 8u ? 3u * a + 2u : 31u, hi = a >= 8u ? 3u * (a - 8u) + 2u : 31u;
+		const uint32_t half = 24u - (a < 8u ? 2u : 1u);			// index bits the first window consumes
+		t.e[p] = Bc6hPartEntry{ (uint32_t)kPartition1BitCx[p] << 12, lo | (hi << 5) | ((82u + half - 96u) << 10), 0xFFFFFFFFu << 2, 0xFFFFFFFFu,
+			bptc_weight_mul(3), bptc_weight_add(3), 7u, 3u };
+	}
+	t.e[32] = Bc6hPartEntry{ 0u, 31u | (31u << 5) | (0u << 10), 0xFFFFFFFFu << 3, 0u, bptc_weight_mul(4), bptc_weight_add(4), 15u, 4u };
+	return t;
+}
+__constant__ Bc6hPartTable kBc6hPartTable = bc6h_part_table();
+
+// ---- LDS: per-lane blend rows at an aligned base (row address = v_bitop3 of the pre-shifted partition word), the
+// partition table and the mode words; workgroup copies made by prepare() (dev_common.h: prepare_tables)
 #if defined(__HIPCC__)
-DH Bc6hModeWords *bc6h_mode_words_lds() { __shared__ Bc6hModeWords t[14]; return t; }
+struct Bc6hLds {
+	uint4 row_a[2][256];		// per lane and subset: base r, g, b, diff r		(subset stride 4096: address bit 12)
+	uint2 row_b[2][256];		//                      diff g, b			(subset stride 2048: address bit 11)
+	Bc6hPartEntry part[33];
+	Bc6hModeWords modes[14];
+};
+DH Bc6hLds &bc6h_lds() { __shared__ __attribute__((aligned(8192))) Bc6hLds s; return s; }
 DH void bc6h_prepare() {
-	if (threadIdx.x >= 200u && threadIdx.x < 214u) bc6h_mode_words_lds()[threadIdx.x - 200u] = kBc6hModeWords[threadIdx.x - 200u];
-	bptc_anchor_p1_prepare();
+	Bc6hLds &s = bc6h_lds();
+	const uint32_t k = threadIdx.x;
+	if (k >= 200u && k < 214u) s.modes[k - 200u] = kBc6hModeWords[k - 200u];
+	{
+		constexpr uint32_t kWords = sizeof(Bc6hPartTable) / 4u;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc6hPartTable);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(s.part);
+		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
+	}
 	__syncthreads();
 }
-DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_mode_words_lds()[mode]; }
+DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_lds().modes[mode]; }
+struct Bc6hLane {
+	uint32_t base_a, base_b;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+	typedef __attribute__((address_space(3))) u32x4 lds_u4;
+	typedef __attribute__((address_space(3))) u32x2 lds_u2;
+	DH Bc6hLane() {
+		Bc6hLds &s = bc6h_lds();
+		base_a = (uint32_t)(uintptr_t)&s.row_a[0][threadIdx.x];
+		base_b = (uint32_t)(uintptr_t)&s.row_b[0][threadIdx.x];
+	}
+	DH void put(int sub, uint4 a, uint2 b) const {
+		((lds_u4 *)(uintptr_t)base_a)[sub * 256] = u32x4{ a.x, a.y, a.z, a.w };
+		((lds_u2 *)(uintptr_t)base_b)[sub * 256] = u32x2{ b.x, b.y };
+	}
+	// sel12 / sel11: any words with the texel's subset bit at bit 12 / bit 11
+	DH void get(uint32_t sel12, uint32_t sel11, uint4 &a, uint2 &b) const {
+		const u32x4 va = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel12, 0x1000u, base_a, 0xEA);
+		const u32x2 vb = *(const lds_u2 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel11, 0x800u, base_b, 0xEA);
+		a = uint4{ va.x, va.y, va.z, va.w }; b = uint2{ vb.x, vb.y };
+	}
+	static DH const Bc6hPartEntry &part(uint32_t i) { return bc6h_lds().part[i]; }
+};
 #else
 DH void bc6h_prepare() {}
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return kBc6hModeWords[mode]; }
+struct Bc6hLane {
+	uint4 ra[2]; uint2 rb[2];
+	DH void put(int sub, uint4 a, uint2 b) { ra[sub] = a; rb[sub] = b; }
+	DH void get(uint32_t sel12, uint32_t sel11, uint4 &a, uint2 &b) const { a = ra[(sel12 >> 12) & 1u]; b = rb[(sel11 >> 11) & 1u]; }
+	static DH const Bc6hPartEntry &part(uint32_t i) { return kBc6hPartTable.e[i]; }
+};
 #endif
 
 DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t (&ep)[3][4]) {
@@ -291,23 +360,23 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 #pragma unroll
 			for (int c = 0; c < 3; c++) { endpoint(c, 2); endpoint(c, 3); }
 		}
-		// partition (5 bits at block bit 77), anchor, index stream (:535-564)
-		const uint32_t part = two ? ubfe(blk.z, 13, 5) : 0u;
-		const uint32_t an = bptc_anchor_p1(part);		// anchor nibbles | one-bit partition << 16
-		const uint32_t pmask = two ? (an >> 16) : 0u;
-		const uint32_t amask = 1u | (two ? (1u << (an & 0xFu)) : 0u);
-		const uint32_t ibits = two ? 3u : 4u;
-		// Index stream, LSB-first, read through two 32-bit windows: texels 0-7 consume 8*ibits - (anchors among
-		// them) <= 31 bits (texel 0 is always an anchor), texels 8-15 start where they ended, and that second window
-		// lies in the last dword (bit 96 / 104 / 105) -- so advancing the stream is one plain shift per texel.
-		const uint32_t lo = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
-		const uint32_t hi = blk.w >> (two ? 10u - (uint32_t)__builtin_popcount(amask & 0xFFu) : 0u);
-		const WeightMad wm = weight_mad(ibits);
+		// partition (5 bits at block bit 77), anchors, index stream (:535-564)
+		const Bc6hPartEntry &pe = Bc6hLane::part(two ? ubfe(blk.z, 13, 5) : 32u);
+		// Index stream, LSB-first, read through two 32-bit windows: texels 0-7 consume 8*ibits - (anchors among them) <= 31
+		// bits (texel 0 is always an anchor), texels 8-15 start where they ended, and that second window lies in the last
+		// dword.  The anchors' absent top bits are then inserted as zeros (w + (w & himask): two full-rate ops each), so
+		// every texel reads its index at a regular position: one `and`, one shift.
+		const uint32_t route = pe.route, ones = pe.ones;		// shifts use the low 5 bits of their amount
+		uint32_t win = two ? field_at<82, 32>(b) : field_at<65, 32>(b);
+		uint32_t win_hi = blk.w >> (route >> 10);
+		win += win & pe.himask0;
+		win += win & (ones << (route & 31u));
+		win_hi += win_hi & (ones << ((route >> 5) & 31u));
+		const uint32_t ibits = pe.ibits, imask = pe.imask, wmul = pe.wmul, wadd = pe.wadd;
 		// ((64-w)*e0 + w*e1 + 32) >> 6  ==  (64*e0 + 32 + w*(e1-e0)) >> 6  (:97-108): per subset keep
 		// base = 64*e0 + 32 and diff = e1 - e0 (a texel channel is one v_mad_i32_i24 + one shift) in per-lane LDS
-		// rows, fetched per texel by the partition bit (dev_common.h: LaneRows)
-		LaneRows<uint4, 2, 81> row_a;		// base r, g, b, diff r
-		LaneRows<uint2, 2, 82> row_b;		// diff g, b
+		// rows, fetched per texel by the partition bit
+		Bc6hLane lane;
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
 			if (s == 1 && !wave_two) break;
@@ -318,19 +387,17 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			ra.w = (uint32_t)(q[0][2 * s + 1] - q[0][2 * s]);
 			rb.x = (uint32_t)(q[1][2 * s + 1] - q[1][2 * s]);
 			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
-			row_a.put(s, ra);
-			row_b.put(s, rb);
+			lane.put(s, ra, rb);
 		}
-		uint32_t win = lo, b_even = 0;
+		const uint32_t p12 = pe.pmask12, p11 = p12 >> 1;
+		uint32_t b_even = 0;
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
-			if (i == 8) win = hi;
-			const uint32_t width = ibits - ((amask >> i) & 1u);	// anchor texels store one bit less
-			const int32_t w = (int32_t)((DETEX_UMUL24(ubfe(win, 0, width), wm.mul) + wm.add) >> 16);
-			win >>= width;
-			const uint32_t sub = (pmask >> i) & 1u;
-			const uint4 ra = row_a.get(sub);
-			const uint2 rb = row_b.get(sub);
+			if (i == 8) win = win_hi;
+			const int32_t w = (int32_t)((DETEX_UMUL24(win & imask, wmul) + wadd) >> 16);
+			win >>= ibits;
+			uint4 ra; uint2 rb;
+			lane.get(p12 >> i, p11 >> i, ra, rb);
 			const int32_t bs[3] = { (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z }, df[3] = { (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y };
 			int32_t v[3];
 #pragma unroll
