@@ -236,15 +236,20 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 	}
 }
 
-// the block of lane i as ONE 8/16-byte load (left to itself the compiler loads the first dword, tests the
-// decoders' early-outs on it and only then fetches the rest: two dependent HBM round trips per block)
+// The block of lane i as ONE 8/16-byte load: left to itself the compiler loads the first dword, tests the decoders'
+// early-outs on it and only then fetches the rest -- two dependent HBM round trips per block.  pin_block() makes all
+// dwords of the word live at one point (an empty asm; no instruction), which keeps the load whole; it is also where
+// the wave waits for the data, so a caller can put work between the request and the pin.
+template <class Word> DH void pin_block(Word &blk) {
+#if defined(__HIPCC__)
+	if constexpr (sizeof(Word) == 16) asm volatile("" : "+v"(blk.x), "+v"(blk.y), "+v"(blk.z), "+v"(blk.w));
+	else asm volatile("" : "+v"(blk.x), "+v"(blk.y));
+#endif
+}
 template <class Dec> DH typename BlockWord<Dec::kBlockBytes>::type load_block(const void *blocks, uint32_t i) {
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
 	Word blk = reinterpret_cast<const Word *>(blocks)[i];
-#if defined(__HIPCC__)
-	if constexpr (Dec::kBlockBytes == 16) asm volatile("" : "+v"(blk.x), "+v"(blk.y), "+v"(blk.z), "+v"(blk.w));
-	else asm volatile("" : "+v"(blk.x), "+v"(blk.y));
-#endif
+	pin_block(blk);
 	return blk;
 }
 
@@ -289,11 +294,18 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	// the first block is requested before the table copy, so its HBM round trip overlaps the copy and the barrier
+	// First block: persistent grids request it BEFORE the table copy and wait for it after the barrier (the copy is 7.5 KiB
+	// there); one-tile workgroups load it after the barrier, as in round 1 -- requesting it earlier made the workgroup's
+	// barrier wait for its slowest wave's HBM load (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 against the round-1
+	// library in the same run).  Loads are unconditional, with the index clamped into the stream: a load under a branch
+	// makes the compiler wait for it at the end of the branch.
 	const uint32_t first = blockIdx.x * 256u + threadIdx.x;
-	Word blk = {};
-	if (first < n_blocks) blk = load_block<Dec>(blocks, first);
+	const uint32_t first_clamped = first < n_blocks ? first : n_blocks - 1u;
+	Word blk;
+	if constexpr (PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
 	prepare_tables<Dec>();
+	if constexpr (!PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
+	pin_block(blk);
 	auto decode_tile = [&](uint32_t tile, const Word &cur) {
 		const uint32_t i = tile * 256u + threadIdx.x;
 		if constexpr (ROW == 8 && NT) {
@@ -327,8 +339,9 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 			const Word cur = blk;
 			const uint32_t i_next = (tile + gridDim.x) * 256u + threadIdx.x;
-			if (tile + gridDim.x < n_tiles && i_next < n_blocks) blk = load_block<Dec>(blocks, i_next);
+			blk = reinterpret_cast<const Word *>(blocks)[i_next < n_blocks ? i_next : n_blocks - 1u];	// requested now ...
 			decode_tile(tile, cur);
+			pin_block(blk);											// ... waited for after this tile
 		}
 	}
 }
