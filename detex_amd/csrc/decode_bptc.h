@@ -405,9 +405,10 @@ template <bool UNIFORM> struct DecBPTCT {
 #if defined(DETEXHIP_EXP_BC7_WAVES)
 	static constexpr int kWavesPerSimd = DETEXHIP_EXP_BC7_WAVES;
 #else
-	// <= 72 VGPRs: seven waves per SIMD (eight would spill; measured 59 vs 65 us on stream U).  LDS (<= 20 KiB per
-	// workgroup) would admit eight workgroups per CU.
-	static constexpr int kWavesPerSimd = 7;
+	// <= 80 VGPRs: six waves per SIMD.  Same-run measurements on stream U / C: 64 VGPRs (9 dwords spilled) 65 / 52.4 us;
+	// 72 VGPRs 59.1 / 52.7 before the next tile's block was really prefetched, 59.1 / 52.2 with it (two dwords spilled,
+	// +2.5 % HBM traffic); 80 VGPRs (no spill) 57.9 / 50.8.  LDS (<= 20 KiB per workgroup) would admit eight workgroups.
+	static constexpr int kWavesPerSimd = 6;
 #endif
 #if defined(DETEXHIP_EXP_BC7_NONPERSISTENT)	// measurement build
 	static constexpr bool kPersistent = false;

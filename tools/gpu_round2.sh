@@ -22,6 +22,8 @@ echo "== BC7 / BC6H old-vs-new (A/B build)"
 DETEXHIP_LIB=$ROOT/detex_amd/lib/libdetexhip_ab.so DETEXHIP_VARIANT=4 timeout 300 python tools/gpu_time.py BPTC U,M,C linear 8192 r01_decoder_variant4 2>>$OUT/bench.err | tee -a $OUT/bc7_ab.jsonl | cut -c1-140
 timeout 300 python tools/gpu_time.py BPTC U,M,C linear 8192 r02_decoder 2>>$OUT/bench.err | tee -a $OUT/bc7_ab.jsonl | cut -c1-140
 DETEXHIP_LIB=$ROOT/detex_amd/lib/libdetexhip_ab.so timeout 300 python -m pytest tests/test_ab_variants.py -m gpu -q -p no:cacheprovider 2>&1 | tail -2 | tee $OUT/pytest_ab.log
+echo "== round-1 library (commit 0ebf32e built into detex_amd/lib/libdetexhip_r01.so) vs this one, same run"
+[ -f detex_amd/lib/libdetexhip_r01.so ] && bash tools/gpu_cmp_r01.sh 2>&1 | tail -14 | tee $OUT/r01_vs_r02_same_run.txt
 echo "== decode without stores / stores without decode (measurement builds)"
 for lib in libdetexhip libdetexhip_exp_nostore libdetexhip_exp_nocompute; do DETEXHIP_LIB=$ROOT/detex_amd/lib/$lib.so timeout 300 python tools/gpu_time.py BPTC,BPTC_SIGNED_FLOAT,BPTC_FLOAT,ETC2_EAC,RGTC1,BC3,BC1 U 2>>$OUT/bench.err | tee -a $OUT/compute_vs_memory.jsonl | cut -c1-130; done
 echo "== mode histograms"; timeout 300 python tools/bench_histogram.py 2>/dev/null | tee $OUT/histogram.txt | cut -c1-120
