@@ -219,10 +219,17 @@ DH void bc7_prepare() {
 struct Bc7Lane {
 #if defined(__HIPCC__)
 	uint32_t bits_base, subset_base;	// LDS byte addresses of this lane's column
+	uint32_t subset_bits;			// 0x3000 in a VGPR (see get_subset)
 	DH Bc7Lane() {
 		Bc7Lds &s = bc7_lds();
 		bits_base = (uint32_t)(uintptr_t)&s.bits[0][threadIdx.x];
 		subset_base = (uint32_t)(uintptr_t)&s.subset[0][threadIdx.x];
+		subset_bits = 0x3000u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
+		// v_bitop3_b32 is VOP3 and takes no literal on gfx950: the compiler would keep the mask in an SGPR, and a full-rate
+		// VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr / bitop3_sgpr)
+		asm volatile("" : "+v"(subset_bits));
+#endif
 	}
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
 	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -246,7 +253,7 @@ struct Bc7Lane {
 	DH void put_subset(int s, uint4 v) const { ((lds_u4 *)(uintptr_t)subset_base)[s * 256] = u32x4{ v.x, v.y, v.z, v.w }; }
 	// sel: any word with the subset number at bits 12-13
 	DH uint4 get_subset(uint32_t sel) const {
-		const u32x4 v = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel, 0x3000u, subset_base, 0xEA);
+		const u32x4 v = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel, subset_bits, subset_base, 0xEA);
 		return uint4{ v.x, v.y, v.z, v.w };
 	}
 	static DH const Bc7Rec &rec(uint32_t r) {

@@ -216,10 +216,17 @@ struct Bc6hLane {
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 	typedef __attribute__((address_space(3))) u32x4 lds_u4;
 	typedef __attribute__((address_space(3))) u32x2 lds_u2;
+	uint32_t bit12, bit11;		// the two subset strides, held in VGPRs: see get()
 	DH Bc6hLane() {
 		Bc6hLds &s = bc6h_lds();
 		base_a = (uint32_t)(uintptr_t)&s.row_a[0][threadIdx.x];
 		base_b = (uint32_t)(uintptr_t)&s.row_b[0][threadIdx.x];
+		bit12 = 0x1000u; bit11 = 0x800u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
+		// v_bitop3_b32 is VOP3 (no literal operand on gfx950): left alone the compiler keeps the masks in SGPRs, and a
+		// full-rate VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr, bitop3_sgpr)
+		asm volatile("" : "+v"(bit12), "+v"(bit11));
+#endif
 	}
 	DH void put(int sub, uint4 a, uint2 b) const {
 		((lds_u4 *)(uintptr_t)base_a)[sub * 256] = u32x4{ a.x, a.y, a.z, a.w };
@@ -227,8 +234,8 @@ struct Bc6hLane {
 	}
 	// sel12 / sel11: any words with the texel's subset bit at bit 12 / bit 11
 	DH void get(uint32_t sel12, uint32_t sel11, uint4 &a, uint2 &b) const {
-		const u32x4 va = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel12, 0x1000u, base_a, 0xEA);
-		const u32x2 vb = *(const lds_u2 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel11, 0x800u, base_b, 0xEA);
+		const u32x4 va = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel12, bit12, base_a, 0xEA);
+		const u32x2 vb = *(const lds_u2 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel11, bit11, base_b, 0xEA);
 		a = uint4{ va.x, va.y, va.z, va.w }; b = uint2{ vb.x, vb.y };
 	}
 	static DH const Bc6hPartEntry &part(uint32_t i) { return bc6h_lds().part[i]; }
@@ -298,10 +305,11 @@ DH int32_t bc6h_unquantize_signed(int32_t x, uint32_t epb) {
 }
 
 // both signed 16-bit lanes: two's complement -> sign-magnitude half of trunc(v * 31 / 32) (decompress-bptc-float.c:576-609)
-DH uint32_t bc6h_sign_magnitude_pk(uint32_t p) {
+// sign_bits = 0x80008000 in a VGPR (Bc6hLane::bit12 explains why)
+DH uint32_t bc6h_sign_magnitude_pk(uint32_t p, uint32_t sign_bits) {
 	const uint32_t a = pk_max16(p, pk_sub16(0u, p));				// |v| (0x8000 stays 0x8000: read as unsigned below)
 	const uint32_t m = pk_sub16(a, pk_lshr16(pk_add16(a, 0x001F001Fu), 5));	// |v| - ceil(|v| / 32) <= 0x7C00
-	return m | and3(pk_add16(m, 0x7FFF7FFFu), p, 0x80008000u);
+	return m | and3(pk_add16(m, 0x7FFF7FFFu), p, sign_bits);
 }
 
 // SWITCH_SCATTER = true keeps the per-mode switch (cheaper when a whole wave shares one mode); the
@@ -352,7 +360,11 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 				const uint32_t raw = delta[c] ? t : ep[c][e];
 				v = SIGNED ? sbfe(raw, 0, p.epb) : (int32_t)raw;
 			}
+#if defined(DETEXHIP_EXP_NO_UNQUANTIZE)	// measurement build (WRONG results): upper bound of a table-driven unquantisation
+			q[c][e] = v;
+#else
 			q[c][e] = SIGNED ? bc6h_unquantize_signed(v, p.epb) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
+#endif
 		};
 #pragma unroll
 		for (int c = 0; c < 3; c++) { endpoint(c, 0); endpoint(c, 1); q[c][2] = 0; q[c][3] = 0; }
@@ -381,16 +393,23 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		for (int s = 0; s < 2; s++) {
 			if (s == 1 && !wave_two) break;
 			uint4 ra; uint2 rb;
-			ra.x = (uint32_t)(q[0][2 * s] * 64 + 32);
-			ra.y = (uint32_t)(q[1][2 * s] * 64 + 32);
-			ra.z = (uint32_t)(q[2][2 * s] * 64 + 32);
-			ra.w = (uint32_t)(q[0][2 * s + 1] - q[0][2 * s]);
-			rb.x = (uint32_t)(q[1][2 * s + 1] - q[1][2 * s]);
-			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
+			// signed: everything times 4, so that the 16 result bits of (base + w * diff) >> 6 are bytes 1-2 of the sum
+			// (|sum| < 2^23, 4 * |diff| < 2^19: still inside v_mad_i32_i24's operands) and one v_perm_b32 both drops the
+			// six fraction bits and packs two channels -- no shifts in the texel loop
+			constexpr int kScale = SIGNED ? 4 : 1;
+			ra.x = (uint32_t)(q[0][2 * s] * (64 * kScale) + 32 * kScale);
+			ra.y = (uint32_t)(q[1][2 * s] * (64 * kScale) + 32 * kScale);
+			ra.z = (uint32_t)(q[2][2 * s] * (64 * kScale) + 32 * kScale);
+			ra.w = (uint32_t)((q[0][2 * s + 1] - q[0][2 * s]) * kScale);
+			rb.x = (uint32_t)((q[1][2 * s + 1] - q[1][2 * s]) * kScale);
+			rb.y = (uint32_t)((q[2][2 * s + 1] - q[2][2 * s]) * kScale);
 			lane.put(s, ra, rb);
 		}
 		const uint32_t p12 = pe.pmask12, p11 = p12 >> 1;
-		uint32_t b_even = 0;
+		uint32_t b_even = 0, sign_bits = 0x80008000u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
+		if (SIGNED) asm volatile("" : "+v"(sign_bits));
+#endif
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			if (i == 8) win = win_hi;
@@ -401,16 +420,17 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			const int32_t bs[3] = { (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z }, df[3] = { (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y };
 			int32_t v[3];
 #pragma unroll
-			for (int c = 0; c < 3; c++) v[c] = (bs[c] + __mul24(w, df[c])) >> 6;
+			for (int c = 0; c < 3; c++) v[c] = SIGNED ? bs[c] + __mul24(w, df[c]) : (bs[c] + __mul24(w, df[c])) >> 6;
 			if (SIGNED) {
 				// :576-609 sign-magnitude half: m = (|v|*31)>>5 = |v| - ceil(|v|/32), sign bit only if m != 0.  Every v fits a
 				// signed 16-bit lane (|v| <= 0x8000, and 0x8000 still comes out right in the unsigned steps), so R,G of this
 				// texel and B of two neighbouring texels are finished two per VGPR; bit 15 of m + 0x7FFF is set iff m != 0.
-				d[2 * i] = bc6h_sign_magnitude_pk(pack16((uint32_t)v[0], (uint32_t)v[1]));
+				// v[] are the sums times 4 here: value c = bits 8-23
+				d[2 * i] = bc6h_sign_magnitude_pk(perm((uint32_t)v[1], (uint32_t)v[0], 0x06050201u), sign_bits);
 				if ((i & 1) == 0) {
 					b_even = (uint32_t)v[2];
 				} else {
-					const uint32_t hb = bc6h_sign_magnitude_pk(pack16(b_even, (uint32_t)v[2]));
+					const uint32_t hb = bc6h_sign_magnitude_pk(perm((uint32_t)v[2], b_even, 0x06050201u), sign_bits);
 					d[2 * i - 1] = hb & 0xFFFFu;		// X = 0
 					d[2 * i + 1] = hb >> 16;
 				}

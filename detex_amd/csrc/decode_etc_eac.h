@@ -122,7 +122,11 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 			if (!(mode_mask & need)) return false;
 		}
 	}
+#if defined(DETEXHIP_EXP_NO_PLANAR)	// measurement build (WRONG results): upper bound of what moving the planar path out of the wave buys
+	if (false) {
+#else
 	if (mode_planar) {
+#endif
 		// :287-317: O, H, V in 6-7-6 bits, MSB-replicated to 8; texel = clamp255((x(H-O) + y(V-O) + 4O + 2) >> 2).
 		// Every term fits a signed 16-bit lane (|sum| <= 2550), so a texel is three packed adds shared
 		// between channels / neighbours, an arithmetic shift and the saturating pack.

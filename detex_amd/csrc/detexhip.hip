@@ -152,6 +152,15 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 		hipError_t ab_result;
 		if (g.variant != 0 && ab_launch_linear<Dec, EPI>(g, &ab_result)) return ab_result;
 #endif
+		// narrow pixels (RGTC1, SIGNED_RGTC1): several blocks per lane, so that a store instruction covers a longer run
+		constexpr int kRow = EpilogueOf<Dec, EPI>::kRowDwords, kGroup = kRow * LaneBlocks<Dec>::value <= 4 ? LaneBlocks<Dec>::value : 1;
+		if constexpr (kGroup > 1 && !PersistentTiles<Dec>::value) {
+			if (g.wb % kGroup == 0 && (reinterpret_cast<uintptr_t>(px) | g.pitch) % (4u * kRow * kGroup) == 0) {
+				hipLaunchKernelGGL((decode_linear_grouped<Dec, EPI, true, kGroup>), dim3((n / kGroup + 255u) / 256u), dim3(256), 0, g.stream,
+					g.blocks, px, g.wb, n, g.pitch, g.status);
+				return hipGetLastError();
+			}
+		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
 		auto kernel = decode_linear<Dec, EPI, true>;
 		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);

@@ -179,6 +179,32 @@ def test_random_stream_vs_oracle(fmt, torch_cuda, oracle):
     assert np.array_equal(got_t.cpu().numpy(), want_t)
 
 
+NARROW = [f for f in F.FORMATS if f.pixel_bytes <= 2]
+
+
+@pytest.mark.parametrize("fmt", NARROW, ids=lambda f: f.name)
+def test_narrow_pixel_grouped_rows(fmt, torch_cuda, oracle):
+    """1- and 2-byte pixels take the several-blocks-per-lane kernel when width_in_blocks % G == 0 and rows are 16-byte
+    aligned, the one-block-per-lane kernel otherwise: block-row widths on both sides of the condition, group counts that
+    do not fill the last workgroup, padded pitches (aligned and not), a canary after every row."""
+    from detex_amd import binding
+    torch = torch_cuda
+    px = fmt.pixel_bytes
+    for wb, hb, pad in [(4, 3, 0), (6, 5, 0), (7, 2, 0), (20, 9, 16), (257, 3, 0), (258, 3, 8), (260, 5, 32), (1028, 2, 4), (64, 33, 0)]:
+        W, H = wb * 4, hb * 4
+        data = ol.stream_u(fmt, wb * hb, seed=0x6A0 + 131 * wb + fmt.index)
+        ok_o, want = oracle.linear(fmt, data, W, H)
+        pitch = W * px + pad
+        out = torch.full((H * pitch,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        binding.decompress_linear_device(fmt, _dev(torch, data), W, H, out=out, pitch=pitch, status=status)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(H, pitch)
+        assert np.array_equal(got[:, :W * px].reshape(-1), want.reshape(-1)), (fmt.name, wb, hb, pad)
+        assert (got[:, W * px:] == 0xA5).all(), (fmt.name, wb, hb, pad)
+        assert bool(status.item() == 0) == ok_o
+
+
 @pytest.mark.parametrize("name,pf", [(f.name, pf) for f in F.FORMATS for pf in F.accepted_pixel_formats(f) if F.epilogue_kind(f, pf)])
 def test_epilogue_targets_random_stream(name, pf, torch_cuda, oracle):
     """in-kernel pixel-format epilogues (BGRA8/BGRX8/RGB8, FLOAT_BGRX16) vs oracle decode + convert"""

@@ -89,6 +89,19 @@ KERNEL(cmp_only, "v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 s[20:21], %1, %5\n v_c
 KERNEL(pk_mul_lo, "v_pk_mul_lo_u16 %0, %0, %4\n v_pk_mul_lo_u16 %1, %1, %5\n v_pk_mul_lo_u16 %2, %2, %4\n v_pk_mul_lo_u16 %3, %3, %5")
 KERNEL(pk_min_max, "v_pk_max_i16 %0, %0, %4\n v_pk_min_i16 %1, %1, %5\n v_pk_max_i16 %2, %2, %4\n v_pk_min_i16 %3, %3, %5")
 KERNEL(v_lshrrev_b64, "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %5\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %5")
+// fast-class ops with one SGPR source (round 2: the compiler keeps VOP3 constants such as bitop3's mask in SGPRs)
+KERNEL(bitop3_sgpr, "v_bitop3_b32 %0, %0, s20, %5 bitop3:0xea\n v_bitop3_b32 %1, %1, s21, %4 bitop3:0xea\n v_bitop3_b32 %2, %2, s20, %5 bitop3:0xea\n v_bitop3_b32 %3, %3, s21, %4 bitop3:0xea")
+KERNEL(bitop3_inline, "v_bitop3_b32 %0, %0, 16, %5 bitop3:0xea\n v_bitop3_b32 %1, %1, 32, %4 bitop3:0xea\n v_bitop3_b32 %2, %2, 16, %5 bitop3:0xea\n v_bitop3_b32 %3, %3, 32, %4 bitop3:0xea")
+KERNEL(add_sgpr, "v_add_u32 %0, s20, %0\n v_add_u32 %1, s21, %1\n v_add_u32 %2, s20, %2\n v_add_u32 %3, s21, %3")
+KERNEL(xor_sgpr, "v_xor_b32 %0, s20, %0\n v_xor_b32 %1, s21, %1\n v_xor_b32 %2, s20, %2\n v_xor_b32 %3, s21, %3")
+KERNEL(lshr_sgpr_amt, "v_lshrrev_b32 %0, s20, %0\n v_lshrrev_b32 %1, s21, %1\n v_lshrrev_b32 %2, s20, %2\n v_lshrrev_b32 %3, s21, %3")
+KERNEL(lshr_sgpr_val, "v_lshrrev_b32 %0, %4, s20\n v_lshrrev_b32 %1, %5, s21\n v_lshrrev_b32 %2, %4, s20\n v_lshrrev_b32 %3, %5, s21")
+KERNEL(mov_sgpr, "v_mov_b32 %0, s20\n v_mov_b32 %1, s21\n v_mov_b32 %2, s20\n v_mov_b32 %3, s21")
+KERNEL(sub_sgpr, "v_sub_u32 %0, s20, %0\n v_sub_u32 %1, s21, %1\n v_sub_u32 %2, s20, %2\n v_sub_u32 %3, s21, %3")
+KERNEL(and_vcc_lo, "v_and_b32 %0, vcc_lo, %0\n v_and_b32 %1, vcc_hi, %1\n v_and_b32 %2, vcc_lo, %2\n v_and_b32 %3, vcc_hi, %3")
+KERNEL(dpp_mov, "v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL(lshl_inline, "v_lshlrev_b32 %0, 2, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 2, %2\n v_lshlrev_b32 %3, 3, %3")
+KERNEL(add_self, "v_add_u32 %0, %0, %0\n v_add_u32 %1, %1, %1\n v_add_u32 %2, %2, %2\n v_add_u32 %3, %3, %3")
 
 struct Entry { const char *name; void (*fn)(uint32_t *, uint32_t, int); };
 #define E(NAME) { #NAME, k_##NAME }
@@ -99,7 +112,8 @@ int main() {
 		E(add_e64), E(and_literal), E(and_inline), E(and_sgpr), E(bfe_inline), E(bfe_sgpr), E(perm_sgpr_sel), E(v_mov), E(v_sat_pk), E(v_pk_add_u16),
 		E(v_pk_ashr), E(v_lshl_add), E(v_add3), E(v_xor), E(v_sub), E(v_lshlrev), E(v_min_max), E(v_ffbl), E(mix_add_bfe), E(mix_valu_salu), E(mix_add_salu),
 		E(lshl_vgpr), E(lshr_inline), E(ashr_inline), E(v_or), E(v_not), E(v_bitop3), E(v_bcnt), E(and_sdwa), E(add_sdwa), E(mov_sdwa), E(add_lit), E(max_u32),
-		E(cmp_only), E(pk_mul_lo), E(pk_min_max) };
+		E(cmp_only), E(pk_mul_lo), E(pk_min_max),
+		E(bitop3_sgpr), E(bitop3_inline), E(add_sgpr), E(xor_sgpr), E(lshr_sgpr_amt), E(lshr_sgpr_val), E(mov_sgpr), E(sub_sgpr), E(and_vcc_lo), E(dpp_mov), E(lshl_inline), E(add_self) };
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount, blocks = cus * 8, iters = 512;	// 8 blocks x 4 waves = 32 waves/CU = 8 per SIMD
 	const double clk = prop.clockRate * 1e3;
