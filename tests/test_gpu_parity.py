@@ -205,6 +205,65 @@ def test_narrow_pixel_grouped_rows(fmt, torch_cuda, oracle):
         assert bool(status.item() == 0) == ok_o
 
 
+def _etc2_is_planar(colour_bytes):
+    """ETC2 mode selection (decompress-etc.c:324-366) on the 8 colour bytes of each block: differential bit set,
+    R and G sums in range, B sum out of range."""
+    b = colour_bytes.astype(np.int32)
+
+    def total(x):
+        d = x & 7
+        return (x >> 3) + np.where(d & 4, d - 8, d)
+    r, g, bl = total(b[:, 0]), total(b[:, 1]), total(b[:, 2])
+    inr = lambda v: (v >= 0) & (v <= 31)
+    return ((b[:, 3] & 2) != 0) & inr(r) & inr(g) & ~inr(bl)
+
+
+@pytest.mark.parametrize("name", ["ETC2", "ETC2_PUNCHTHROUGH", "ETC2_EAC"])
+def test_etc2_planar_blocks_per_wave(name, torch_cuda, oracle):
+    """A wave with up to eight planar blocks decodes them cooperatively (one texel per lane through LDS), a wave with more
+    decodes them in their own lanes: streams with 0..10, 63 and 64 planar blocks per group of 64, at the start, the end and
+    scattered positions, linear and block-major layouts, ragged block counts, and the per-block API with the planar mode
+    masked out (those blocks fail before the cooperative part)."""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    bb = fmt.block_bytes
+    pool = ol.stream_u(fmt, 1 << 16, seed=0x91A7A + fmt.index).reshape(-1, bb)
+    planar = _etc2_is_planar(pool[:, bb - 8:])
+    if name == "ETC2":                                            # the classifier above against the restated detexGetModeETC2
+        assert np.array_equal(planar, oracle.modes(fmt, pool.reshape(-1)) == 4)
+    p_pool, o_pool = pool[planar], pool[~planar]
+    assert len(p_pool) > 1000 and len(o_pool) > 20000
+    rng = np.random.default_rng(0x5EED + fmt.index)
+    counts = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 63, 64, 1, 8, 4, 0]
+    waves = []
+    for w, k in enumerate(counts):
+        blk = o_pool[rng.integers(0, len(o_pool), 64)].copy()
+        where = np.arange(k) if w % 3 == 0 else (63 - np.arange(k) if w % 3 == 1 else rng.choice(64, k, replace=False))
+        blk[where] = p_pool[rng.integers(0, len(p_pool), k)]
+        waves.append(blk)
+    data = np.concatenate(waves).reshape(-1)                      # 1024 blocks: 64 x 16 blocks
+    W, H = 256, 64
+    ok_o, want = oracle.linear(fmt, data, W, H)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert bool(status.item() == 0) == ok_o
+    ok_t, want_t = oracle.tiled(fmt, data, W // 4, H // 4)
+    got_t = binding.decompress_tiled_device(fmt, _dev(torch, data), W // 4, H // 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_t.cpu().numpy(), want_t)
+    # ragged counts (the last wave is partly idle) and a mode mask without the planar mode
+    for n in (1, 37, 64, 65, 700, 1023):
+        for mask in (0xFFFFFFFF, 0x0F, 0x10):
+            ok_b, want_b = oracle.blocks(fmt, data[:n * bb], mode_mask=mask)
+            got_b, got_ok = binding.decompress_blocks_device(fmt, _dev(torch, data[:n * bb]), n, mode_mask=mask)
+            torch.cuda.synchronize()
+            assert np.array_equal(got_ok.cpu().numpy()[:n].astype(bool), ok_b), (n, mask)
+            assert np.array_equal(got_b.cpu().numpy().reshape(-1)[:n * 16 * fmt.pixel_bytes], want_b.reshape(-1)), (n, mask)
+
+
 @pytest.mark.parametrize("name,pf", [(f.name, pf) for f in F.FORMATS for pf in F.accepted_pixel_formats(f) if F.epilogue_kind(f, pf)])
 def test_epilogue_targets_random_stream(name, pf, torch_cuda, oracle):
     """in-kernel pixel-format epilogues (BGRA8/BGRX8/RGB8, FLOAT_BGRX16) vs oracle decode + convert"""
