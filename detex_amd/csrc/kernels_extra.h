@@ -95,26 +95,31 @@ template <int CLASS> DH uint32_t block_mode(const uint32_t *w) {	// w = the bloc
 	} else return 0u;
 }
 
-// Persistent grid-stride kernel.  Every lane counts into its OWN column of a [16 modes][256 lanes] LDS table with
-// one ds_add_u32 per block (address = column + mode * 1 KiB: conflict-free, no return value, one VALU op) -- the
+// Persistent grid-stride kernel.  Every lane counts into its OWN column of a [16 modes][1024 lanes] LDS table with
+// one ds_add_u32 per block (address = column + mode * 4 KiB: conflict-free, no return value, one VALU op) -- the
 // round-1 kernel issued 16 ballots + popcounts per block and was SALU-bound.  Eight blocks per lane per trip, all
 // loads issued before the first is classified: the kernel only reads, so its speed is the bytes it keeps in flight.
-// What bounds it now is combining the workgroups: device-scope atomics on the one 64-byte line of the 16 result
-// words serialise at ~8.6 ns each (measured: +2.2 us per pair of non-empty bins per 256 workgroups), so there is one
-// workgroup per CU and two adjacent bins travel in one 64-bit atomic.  (A ticketed "last workgroup sums per-workgroup
-// slots" combine was measured too: 30+ us with agent-scope fences -- every workgroup writes back / invalidates its
-// XCD's L2 -- and 15-21 us with completion-ordered relaxed atomics, no better on average and not provably ordered.)
+// What bounds it is combining the workgroups: device-scope atomics on the one 64-byte line of the 16 result words
+// serialise at ~8.6 ns each, and they all arrive at the end (rocprofv3, 4 Mi blocks, 256 workgroups of 256 lanes:
+// BC7 19.9 us = 10.6 us of reading + 4 pairs of bins x 256 x 8.6 ns; BC1, one pair, 9.4 us).  So the grid is FEW, LARGE
+// workgroups -- 1024 lanes, the same bytes in flight from a quarter of the atomics -- and two adjacent bins travel in one
+// 64-bit atomic.  (A ticketed "last workgroup sums per-workgroup slots" combine was measured too: 30+ us with agent-scope
+// fences -- every workgroup writes back / invalidates its XCD's L2 -- and 15-21 us with completion-ordered relaxed
+// atomics, not provably ordered.)
+constexpr int kHistogramLanes = 1024;
 template <int CLASS, int BLOCK_DWORDS>
-__global__ __launch_bounds__(256) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(kHistogramLanes) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
 		uint32_t *__restrict__ hist) {
 	typedef typename BlockWord<4 * BLOCK_DWORDS>::type Word;
 	constexpr int UNROLL = 8;
-	__shared__ uint32_t bins[16][256];
+	constexpr uint32_t LANES = kHistogramLanes;
+	__shared__ uint32_t bins[16][LANES];
+	__shared__ uint32_t totals[16];
 #pragma unroll
 	for (int m = 0; m < 16; m++) bins[m][threadIdx.x] = 0u;		// own column: no barrier needed before the counting
 	uint32_t *column = &bins[0][threadIdx.x];
-	const uint32_t stride = gridDim.x * 256u;
-	for (uint64_t i = blockIdx.x * 256u + threadIdx.x; i < n_blocks; i += (uint64_t)stride * UNROLL) {	// 64-bit: n_blocks may be close to 2^32
+	const uint32_t stride = gridDim.x * LANES;
+	for (uint64_t i = blockIdx.x * LANES + threadIdx.x; i < n_blocks; i += (uint64_t)stride * UNROLL) {	// 64-bit: n_blocks may be close to 2^32
 		Word v[UNROLL];
 		bool live[UNROLL];
 #pragma unroll
@@ -127,25 +132,26 @@ __global__ __launch_bounds__(256) void mode_histogram(const uint32_t *__restrict
 		for (int k = 0; k < UNROLL; k++) {
 			uint32_t w[BLOCK_DWORDS];
 			__builtin_memcpy(w, &v[k], sizeof w);
-			if (live[k]) __hip_atomic_fetch_add(column + block_mode<CLASS>(w) * 256u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (live[k]) __hip_atomic_fetch_add(column + block_mode<CLASS>(w) * LANES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 	__syncthreads();
-	// row m is summed by the 16 threads 16m .. 16m+15: 16 independent LDS reads each (a staggered start keeps the 16
-	// groups on different banks), then four xor-shuffle steps inside the group
-	const uint32_t m = threadIdx.x >> 4, part = threadIdx.x & 15u;
+	// wave m (of 16) sums row m: 16 LDS reads per lane (consecutive lanes, consecutive words), then a wave reduction
+	const uint32_t m = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint32_t sum = 0;
 #pragma unroll
-	for (int l = 0; l < 16; l++) sum += bins[m][(part * 16u + (uint32_t)l + 4u * m) & 255u];
+	for (int l = 0; l < (int)(LANES / 64u); l++) sum += bins[m][64u * (uint32_t)l + lane];
 #pragma unroll
-	for (int step = 8; step >= 1; step >>= 1) sum += (uint32_t)__shfl_xor((int)sum, step, 16);
-	const uint32_t next = (uint32_t)__shfl_down((int)sum, 16);		// bin m + 1 (same wave: 4 bins per wave)
-	if (part == 0 && (m & 1u) == 0) {		// (no carry between the two halves: a bin counts fewer than 2^32 blocks)
+	for (int step = 32; step >= 1; step >>= 1) sum += (uint32_t)__shfl_xor((int)sum, step, 64);
+	if (lane == 0) totals[m] = sum;
+	__syncthreads();
+	if (threadIdx.x < 8u) {		// (no carry between the two halves: a bin counts fewer than 2^32 blocks)
+		const uint32_t lo = totals[2u * threadIdx.x], hi = totals[2u * threadIdx.x + 1u];
 		if ((reinterpret_cast<uintptr_t>(hist) & 7u) == 0) {
-			if (sum | next) atomicAdd(reinterpret_cast<unsigned long long *>(hist + m), (unsigned long long)sum | ((unsigned long long)next << 32));
+			if (lo | hi) atomicAdd(reinterpret_cast<unsigned long long *>(hist + 2u * threadIdx.x), (unsigned long long)lo | ((unsigned long long)hi << 32));
 		} else {
-			if (sum) atomicAdd(&hist[m], sum);
-			if (next) atomicAdd(&hist[m + 1], next);
+			if (lo) atomicAdd(&hist[2u * threadIdx.x], lo);
+			if (hi) atomicAdd(&hist[2u * threadIdx.x + 1u], hi);
 		}
 	}
 }

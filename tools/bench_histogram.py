@@ -1,11 +1,13 @@
-"""Block-mode histogram (detexhipModeHistogramDevice) over a 2048x2048-block stream, timed by hipGraph replay."""
+"""Block-mode histogram (detexhipModeHistogramDevice) over a side x side block stream (default 2048), timed by hipGraph replay.
+usage: python tools/bench_histogram.py [side_in_blocks]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from detex_amd import binding, formats as F
 import oracle_lib as ol
 for name in ("BPTC", "BC1", "ETC2", "BPTC_FLOAT"):
-    fmt = F.BY_NAME[name]; n = 2048 * 2048
+    side_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    fmt = F.BY_NAME[name]; n = side_blocks * side_blocks
     data = ol.stream_u(fmt, n, seed=5 + fmt.index)
     d = torch.from_numpy(np.ascontiguousarray(data)).cuda()
     h = torch.zeros(16, dtype=torch.int32, device="cuda")
