@@ -26,7 +26,8 @@ echo "== round-1 library (commit 0ebf32e built into detex_amd/lib/libdetexhip_r0
 [ -f detex_amd/lib/libdetexhip_r01.so ] && bash tools/gpu_cmp_r01.sh 2>&1 | tail -14 | tee $OUT/r01_vs_r02_same_run.txt
 echo "== decode without stores / stores without decode (measurement builds)"
 for lib in libdetexhip libdetexhip_exp_nostore libdetexhip_exp_nocompute; do DETEXHIP_LIB=$ROOT/detex_amd/lib/$lib.so timeout 300 python tools/gpu_time.py BPTC,BPTC_SIGNED_FLOAT,BPTC_FLOAT,ETC2_EAC,RGTC1,BC3,BC1 U 2>>$OUT/bench.err | tee -a $OUT/compute_vs_memory.jsonl | cut -c1-130; done
-echo "== mode histograms"; timeout 300 python tools/bench_histogram.py 2>/dev/null | tee $OUT/histogram.txt | cut -c1-120
+echo "== mode histograms (4 Mi and 16 Mi blocks)"; (timeout 300 python tools/bench_histogram.py 2>/dev/null; timeout 300 python tools/bench_histogram.py 4096 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120
+echo "== VALU issue rates"; timeout 120 ./tools/ubench/valu_rates > $OUT/valu_rates.txt 2>&1; tail -12 $OUT/valu_rates.txt
 echo "== mip chains"; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-300 $OUT/mips.json
 echo "== host transfer paths"; timeout 120 ./tools/ubench/host_paths 2>&1 | tee $OUT/host_paths.txt | head -8
 echo "== launch time per 25-launch window + clocks (power-management transient)"; for f in BC1 BPTC BPTC_SIGNED_FLOAT; do timeout 120 python tools/gpu_sustain.py $f 32 2>&1 | tail -2 | cut -c1-900; done | tee $OUT/sustain_windows.txt
