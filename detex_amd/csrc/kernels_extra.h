@@ -99,13 +99,13 @@ template <int CLASS> DH uint32_t block_mode(const uint32_t *w) {	// w = the bloc
 // one ds_add_u32 per block (address = column + mode * 4 KiB: conflict-free, no return value, one VALU op) -- the
 // round-1 kernel issued 16 ballots + popcounts per block and was SALU-bound.  Eight blocks per lane per trip, all
 // loads issued before the first is classified: the kernel only reads, so its speed is the bytes it keeps in flight.
-// What bounds it is combining the workgroups: device-scope atomics on the one 64-byte line of the 16 result words
-// serialise at ~8.6 ns each, and they all arrive at the end (rocprofv3, 4 Mi blocks, 256 workgroups of 256 lanes:
-// BC7 19.9 us = 10.6 us of reading + 4 pairs of bins x 256 x 8.6 ns; BC1, one pair, 9.4 us).  So the grid is FEW, LARGE
-// workgroups -- 1024 lanes, the same bytes in flight from a quarter of the atomics -- and two adjacent bins travel in one
-// 64-bit atomic.  (A ticketed "last workgroup sums per-workgroup slots" combine was measured too: 30+ us with agent-scope
-// fences -- every workgroup writes back / invalidates its XCD's L2 -- and 15-21 us with completion-ordered relaxed
-// atomics, not provably ordered.)
+// Workgroups of 1024 lanes (four waves per SIMD): with 256-lane workgroups, one per CU, the kernel took 19.9 us for 4 Mi
+// BC7 blocks where 64 MiB at the HBM read rate need 10.6 -- one wave per SIMD does not keep enough loads in flight.  The
+// combine is device-scope atomics on the one 64-byte line of the 16 result words (~8.6 ns each, serialised), two adjacent
+// bins per 64-bit atomic, so the grid stays at a few hundred workgroups (detexhip.hip has the sweep: 192-256).
+// (A ticketed "last workgroup sums per-workgroup slots" combine was measured too: 30+ us with agent-scope fences -- every
+// workgroup writes back / invalidates its XCD's L2 -- and 15-21 us with completion-ordered relaxed atomics, not provably
+// ordered.)
 constexpr int kHistogramLanes = 1024;
 template <int CLASS, int BLOCK_DWORDS>
 __global__ __launch_bounds__(kHistogramLanes) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
