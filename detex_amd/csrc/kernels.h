@@ -66,7 +66,23 @@ template <class Dec> struct NativeOf<Dec, std::void_t<decltype(Dec::kNative)>> {
 
 // half bit pattern -> 8-bit component of the FLOAT_RGBX16 -> RGBX16 -> RGBX8 path; filled per device by the host side
 // of the library before the first launch that needs it (detexhip.hip: ensure_half_table)
-__device__ uint8_t kHalfToU8[65536];
+__device__ __attribute__((aligned(16))) uint8_t kHalfToU8[65536];
+// The kernels look halves up in a WORKGROUP COPY of the table's live part: unsigned BC6H decodes to halves 0 .. 0x7BFF
+// (never negative, never Inf / NaN: decompress-bptc-float.c:613-621), and every half from 1.0 = 0x3C00 up converts to 255,
+// so entries 0 .. 0x3C00 with the index clamped cover all of it in 15 KiB of LDS.  48 lookups per block as per-lane
+// gathers from the 64 KiB table in global memory made a wave-wide load instruction touch up to 64 cache lines (8192^2 BC6H
+// -> BGRX8: 244 us); LDS serves the same gather from 32 banks.
+constexpr uint32_t kHalfOne = 0x3C00u;
+constexpr uint32_t kHalfLutBytes = (kHalfOne + 1u + 15u) & ~15u;
+DH uint8_t *half_lut() { __shared__ __attribute__((aligned(16))) uint8_t table[kHalfLutBytes]; return table; }
+DH void half_lut_prepare() {
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	const v4 *src = reinterpret_cast<const v4 *>(kHalfToU8);
+	v4 *dst = reinterpret_cast<v4 *>(half_lut());
+	for (uint32_t k = threadIdx.x; k < kHalfLutBytes / 16u; k += 256u) dst[k] = src[k];
+	__syncthreads();
+}
+DH uint32_t half_to_u8(uint32_t half_bits) { return half_lut()[half_bits < kHalfOne ? half_bits : kHalfOne]; }
 
 // pixel i (0..15) of a decoded block as R | G << 8 | B << 16 | 0xFF << 24
 template <int NC> DH uint32_t pixel_as_rgbx8(const uint32_t *d, int i) {
@@ -80,7 +96,7 @@ template <int NC> DH uint32_t pixel_as_rgbx8(const uint32_t *d, int i) {
 		return component16_to_8(w & 0xFFFFu) | (component16_to_8(w >> 16) << 8) | 0xFF000000u;
 	} else {	// kNatFloatRGBX16: pixel = {R | G << 16, B | X << 16}
 		const uint32_t w0 = d[2 * i], w1 = d[2 * i + 1];
-		return (uint32_t)kHalfToU8[w0 & 0xFFFFu] | ((uint32_t)kHalfToU8[w0 >> 16] << 8) | ((uint32_t)kHalfToU8[w1 & 0xFFFFu] << 16) | 0xFF000000u;
+		return half_to_u8(w0 & 0xFFFFu) | (half_to_u8(w0 >> 16) << 8) | (half_to_u8(w1 & 0xFFFFu) << 16) | 0xFF000000u;
 	}
 }
 
@@ -149,6 +165,10 @@ template <int P, int NC> struct Epilogue<kEpiToRGB8, P, NC> {
 	}
 };
 template <class Dec, int EPI> using EpilogueOf = Epilogue<EPI, Dec::kPixelBytes, NativeOf<Dec>::value>;
+// tables an epilogue needs in LDS: called by every kernel with all 256 threads right after prepare_tables<Dec>()
+template <class Dec, int EPI> DH void prepare_epilogue() {
+	if constexpr (NativeOf<Dec>::value == kNatFloatRGBX16 && EPI >= kEpiToRGBX8) half_lut_prepare();
+}
 
 // one 4-pixel row of ROW dwords; non-temporal (streaming) or ordinary stores
 template <int ROW, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
@@ -308,6 +328,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	Word blk;
 	if constexpr (PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
 	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
 	if constexpr (!PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
 	pin_block(blk);
 	auto decode_tile = [&](uint32_t tile, const Word &cur) {
@@ -367,6 +388,7 @@ __global__ __launch_bounds__(256) void decode_linear_grouped(const void *__restr
 	static_assert(ROW * G == 2 || ROW * G == 4, "a lane writes one 8- or 16-byte vector per texel row");
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
 	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
 	const uint32_t n_groups = n_blocks / G, group = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t first = (group < n_groups ? group : n_groups - 1u) * G;	// unconditional load, index clamped into the stream
 	Word blk[G];
@@ -433,6 +455,7 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
@@ -470,6 +493,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;	// = 16-byte vectors per decoded block
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
 	const uint32_t n_tiles = PersistentTiles<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t i = tile * 256u + threadIdx.x;

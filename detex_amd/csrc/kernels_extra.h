@@ -29,6 +29,7 @@ template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
 	// workgroup -> level: wave-uniform scalar search over <= 16 entries
 	uint32_t l = 0;
 	for (uint32_t k = 1; k < table.n_levels; k++) l = blockIdx.x >= table.wg_start[k] ? k : l;
