@@ -32,14 +32,6 @@ namespace detexhip {
 // pixel-format epilogues a decoder can feed (kernels.h)
 enum : int { kNatRGBA8 = 0, kNatR8, kNatRG8, kNatR16, kNatSignedR16, kNatRG16, kNatSignedRG16, kNatFloatRGBX16, kNatOther };
 
-// 16-bit component -> 8-bit as the reference converts it (convert.c:258-267, 299-313): (x + 127) * 255 / 65535.
-// floor(y / 65535) = (y + (y >> 16) + 1) >> 16 for every y = (x + 127) * 255, x < 65536 (checked exhaustively in
-// tests/test_host_logic.py)
-DETEX_HD uint32_t component16_to_8(uint32_t x) {
-	const uint32_t y = (x + 127u) * 255u;
-	return (y + (y >> 16) + 1u) >> 16;
-}
-
 // ---- exact small-domain unsigned division by multiply-shift (products < 2^24 * 2^16) -----
 DETEX_HD uint32_t div3_u(uint32_t x) { return (x * 43691u) >> 17; }  // exact for x < 98304
 DETEX_HD uint32_t div5_u(uint32_t x) { return (x * 52429u) >> 18; }  // exact for x < 81920
@@ -61,6 +53,11 @@ DETEX_HD uint32_t bptc_weight(uint32_t index, uint32_t bits) {
 #else
 #define DETEX_UMUL24(a, b) (((a) & 0xFFFFFFu) * ((b) & 0xFFFFFFu))
 #endif
+// 16-bit component -> 8-bit as the reference converts it (convert.c:258-267, 299-313): (x + 127) * 255 / 65535
+// = floor((x + 127) / 257) = ((x + 127) * 0xFF01) >> 24 for every x < 65536 (0xFF01 * 257 = 2^24 + 1 and the product stays
+// below 2^32: one v_mad_u32_u24 and a shift; checked exhaustively in tests/test_host_logic.py)
+DETEX_HD uint32_t component16_to_8(uint32_t x) { return ((x & 0xFFFFu) * 0xFF01u + 127u * 0xFF01u) >> 24; }	// (the mask lets the compiler pick the 24-bit multiply)
+
 // division-free: 65535 = 254*258 + 3, so n*65535/254 = n*258 + floor(3n/254) with floor(3n/254) = (n>=85)+(n>=170)+(n>=254)
 DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) {
 	const uint32_t n = (uint32_t)(v + 127);

@@ -57,6 +57,8 @@ extern "C" int check(void) {
 			const uint32_t d = (1u << bits) - 1;
 			if (bptc_weight(i, bits) != (64 * i + d / 2) / d) return 100 + bits;
 		}
+	for (uint32_t x = 0; x < 65536; x++)		// 16 -> 8 bit component of the conversion epilogues (convert.c:258-267)
+		if (component16_to_8(x) != (x + 127) * 255 / 65535) return 150;
 	for (int v = -127; v <= 127; v++)
 		if (rgtc_signed_to_16(v) != (uint32_t)(uint16_t)(int16_t)((v + 127) * 65535 / 254 - 32768)) return 200;
 	// the biased forms used by the signed RGTC decoder (decode_s3tc_rgtc.h: rgtc_channel_s16)
