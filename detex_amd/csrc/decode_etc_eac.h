@@ -142,7 +142,7 @@ template <uint32_t ALPHA> DH uint32_t etc_planar_texel(const EtcPlanar &c, uint3
 // lanes, on the path they always took.  Same run, 8192^2, stream U: ETC2_EAC 52.9 -> 50.4 us, ETC2 44.7 -> 43.1.  Purely wave-local: LDS operations of one wave
 // complete in order, no workgroup barrier; works for any set of active lanes (tasks are dealt to the active ones).
 constexpr int kEtcPlanarShared = 8;	// most planar blocks per wave that are decoded cooperatively (two passes of 64 texels)
-struct alignas(16) EtcPlanarSlab { uint32_t coef[kEtcPlanarShared][8]; uint32_t texel[kEtcPlanarShared][16]; };
+struct alignas(16) EtcPlanarSlab { uint32_t coef[kEtcPlanarShared][8]; uint32_t texel[kEtcPlanarShared * 16]; };	// texel[16 * b + 4 * y + x]
 DH EtcPlanarSlab &etc_planar_slab() { __shared__ EtcPlanarSlab slabs[4]; return slabs[threadIdx.x >> 6]; }
 DH void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -173,13 +173,13 @@ template <uint32_t ALPHA> DH void etc_planar_wave(bool mode_planar, uint64_t own
 		const u32x4 ka = *reinterpret_cast<const u32x4 *>(&slab.coef[t >> 4][0]);
 		const u32x2 kb = *reinterpret_cast<const u32x2 *>(&slab.coef[t >> 4][4]);
 		const EtcPlanar c = { ka.x, ka.y, ka.z, ka.w, kb.x, kb.y };
-		slab.texel[0][t] = etc_planar_texel<ALPHA>(c, t & 3u, (t >> 2) & 3u);		// texel[b][y * 4 + x], b = t / 16
+		slab.texel[t] = etc_planar_texel<ALPHA>(c, t & 3u, (t >> 2) & 3u);
 	}
 	wave_lds_sync();
 	if (mode_planar) {
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
-			const u32x4 v = *reinterpret_cast<const u32x4 *>(&slab.texel[rank][4 * k]);
+			const u32x4 v = *reinterpret_cast<const u32x4 *>(&slab.texel[16u * rank + 4u * (uint32_t)k]);
 			d[4 * k] = v.x; d[4 * k + 1] = v.y; d[4 * k + 2] = v.z; d[4 * k + 3] = v.w;
 		}
 	}
