@@ -186,7 +186,7 @@ struct Bc7Lds {
 	// per-lane block dwords, LAST member: fields that start near the end of the block also read "rows" 4 and 5,
 	// i.e. up to 2 KiB past this array -- LDS reads beyond the allocation return 0 rather than faulting, and whatever
 	// they return stands for bits beyond 127, which no field or index ever consumes
-	uint32_t bits[4][256];
+	alignas(16) uint32_t bits[4][256];	// (16-byte aligned: the block-major exchange stages 16-byte vectors here, stage_slot)
 #if defined(DETEXHIP_EXP_LDS_PAD)		// measurement build: lower the occupancy
 	uint32_t pad[DETEXHIP_EXP_LDS_PAD / 4];
 #endif
@@ -424,6 +424,21 @@ template <bool UNIFORM> struct DecBPTCT {
 #endif
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
+#if !defined(DETEXHIP_EXP_BC7_SEPARATE_STAGE)
+	// 16-byte staging slot of the block-major exchange (kernels.h: decode_blocks) inside this wave's own lane rows, which
+	// are dead once a tile is decoded: vector k (0..3) of the wave's block b (0..63).  Vectors 0-2 live in the wave's
+	// 1 KiB of subset row k, rotated by 2k slots so that the transposed reads (four consecutive lanes = the four vectors
+	// of one block) fall on different banks; vector 3 in the wave's four 256-byte pieces of the block-dword rows.  A
+	// separate 17 KiB staging array left four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
+	static constexpr bool kOwnStage = true;
+	static DH void *stage_slot(uint32_t k, uint32_t b) {
+		Bc7Lds &s = bc7_lds();
+		const uint32_t w = threadIdx.x >> 6, p = (b + 2u * k) & 63u;
+		char *in_rows = reinterpret_cast<char *>(&s.subset[0][64u * w]) + k * (uint32_t)sizeof(s.subset[0]) + p * 16u;
+		char *in_bits = reinterpret_cast<char *>(&s.bits[0][64u * w]) + (p >> 4) * (uint32_t)sizeof(s.bits[0]) + (p & 15u) * 16u;
+		return k < 3u ? in_rows : in_bits;
+	}
+#endif
 #endif
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		if ((blk.x & 0xFFu) == 0u) return false;		// reserved (decompress-bptc.c:229-237, 361)

@@ -33,6 +33,10 @@ template <class Dec> struct PersistentTiles<Dec, std::enable_if_t<Dec::kPersiste
 template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
 template <class Dec> struct WavesPerSimd<Dec, std::enable_if_t<(Dec::kWavesPerSimd > 0)>> { static constexpr int value = Dec::kWavesPerSimd; };
 
+// decoders whose per-lane LDS rows double as the staging area of the block-major exchange (Dec::kOwnStage, Dec::stage_slot)
+template <class Dec, class = void> struct OwnStage { static constexpr bool value = false; };
+template <class Dec> struct OwnStage<Dec, std::enable_if_t<Dec::kOwnStage>> { static constexpr bool value = true; };
+
 // blocks per lane in the linear fast path (Dec::kLaneBlocks; default 1): see decode_linear_grouped
 template <class Dec, class = void> struct LaneBlocks { static constexpr int value = 1; };
 template <class Dec> struct LaneBlocks<Dec, std::enable_if_t<(Dec::kLaneBlocks > 1)>> { static constexpr int value = Dec::kLaneBlocks; };
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
 	const uint32_t n_tiles = PersistentTiles<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
+	// (requesting the next tile's block ahead, as decode_linear does, measured no gain here: 63.6-64.0 vs 62.4-63.0 us on BC7)
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t i = tile * 256u + threadIdx.x;
 		const bool live = i < n_blocks;
@@ -516,10 +521,18 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 			// costs an 8-way conflict on every access for the 128-byte BC6H blocks.  64-bit pixels take two passes
 			// of 32 blocks so that 17 KiB per workgroup suffice for every pixel size.  Lanes past the end of the
 			// stream stay alive for the exchange (a tail wave's data is spread over all its lanes).
+			// BC7 (64-byte blocks) stages inside its own, by then dead, per-lane rows instead (OwnStage).
 			constexpr int PASSES = ROW == 8 ? 2 : 1, GROUP = 64 / PASSES;		// blocks per pass
 			constexpr int STRIDE = GROUP + (16 % ROW == 0 ? 16 / ROW : 5);
-			__shared__ v4 stage[4][ROW * STRIDE];
-			v4 *slab = stage[threadIdx.x >> 6];
+			constexpr bool OWN = OwnStage<Dec>::value && ROW == 4;
+			auto slot = [&](uint32_t k, uint32_t b) -> v4 * {
+				if constexpr (OWN) {
+					return static_cast<v4 *>(Dec::stage_slot(k, b));
+				} else {
+					__shared__ v4 stage[4][ROW * STRIDE];
+					return &stage[threadIdx.x >> 6][k * STRIDE + b];
+				}
+			};
 			const uint32_t lane = threadIdx.x & 63u;
 			uint32_t o[4 * ROW];
 			bool ok = true;
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 			for (int p = 0; p < PASSES; p++) {
 				if (live && (PASSES == 1 || lane / GROUP == (uint32_t)p)) {
 #pragma unroll
-					for (int k = 0; k < ROW; k++) slab[k * STRIDE + lane % GROUP] = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+					for (int k = 0; k < ROW; k++) *slot((uint32_t)k, lane % GROUP) = v4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
 				}
 				// same wave: LDS operations complete in order; the fences keep the compiler from reordering across the exchange
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 				for (int j = 0; j < GROUP * ROW / 64; j++) {
 					const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
 					const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
-					if (g < vectors) __builtin_nontemporal_store(slab[(e % ROW) * STRIDE + e / ROW], out + g);
+					if (g < vectors) __builtin_nontemporal_store(*slot(e % ROW, e / ROW), out + g);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
