@@ -294,14 +294,22 @@ DH int32_t bc6h_unquantize_unsigned(uint32_t x, uint32_t epb) {
 	uint32_t u = x == 0u ? 0u : (x == (1u << epb) - 1u ? 0xFFFFu : mid);
 	return (int32_t)(epb >= 16u ? x : u);
 }
-// decompress-bptc-float.c:65-86
-DH int32_t bc6h_unquantize_signed(int32_t x, uint32_t epb) {
-	const bool neg = x < 0;
-	const uint32_t ax = (uint32_t)(neg ? -x : x);
-	const uint32_t mid = ((ax << 15) + 0x4000u) >> ((epb - 1u) & 31u);
-	const uint32_t u = ax == 0u ? 0u : (ax >= (1u << (epb - 1u)) - 1u ? 0x7FFFu : mid);
-	const int32_t s = neg ? -(int32_t)u : (int32_t)u;
-	return epb >= 16u ? x : s;
+// decompress-bptc-float.c:65-86: sign(x) * U(|x|) with U(0) = 0, U(a) = 0x7FFF for a >= lim = 2^(epb-1) - 1, else
+// ((a << 15) + 0x4000) >> (epb - 1).  Both terms of that middle case are multiples of 2^(epb-1) (epb <= 15 there), so it is
+// (2a + 1) << (15 - epb) exactly, and with the sign:  (2x + sign(x)) << (15 - epb), sign(x) = v_med3_i32(x, -1, 1) -- which is also
+// right at x = 0.  |x| >= lim as one unsigned compare of x + lim - 1 against 2 lim - 1.  Eight instructions where the
+// literal form (absolute value, three compares, three selects, negate) took twelve.
+struct Bc6hSignedUnq { uint32_t shift, lim_m1, lim2_m1; bool passthrough; };	// per block: from epb
+DH Bc6hSignedUnq bc6h_signed_unq(uint32_t epb) {
+	const uint32_t lim = (1u << ((epb - 1u) & 31u)) - 1u;
+	return Bc6hSignedUnq{ (15u - epb) & 31u, lim - 1u, 2u * lim - 1u, epb >= 16u };
+}
+DH int32_t bc6h_unquantize_signed(int32_t x, const Bc6hSignedUnq &k) {
+	const int32_t sign = sign_of(x);
+	// (both sides through opaque(): evaluated unconditionally and chosen by a select -- the compiler otherwise branches)
+	const uint32_t mid = opaque((uint32_t)(2 * x + sign) << k.shift), top = opaque((uint32_t)__mul24(sign, 0x7FFF));
+	const int32_t u = (int32_t)((uint32_t)x + k.lim_m1 >= k.lim2_m1 ? top : mid);
+	return k.passthrough ? x : u;
 }
 
 // both signed 16-bit lanes: two's complement -> sign-magnitude half of trunc(v * 31 / 32) (decompress-bptc-float.c:576-609)
@@ -351,19 +359,34 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		const bool wave_two = __builtin_amdgcn_ballot_w64(two) != 0;
 		const uint32_t delta[3] = { p.dr, p.dg, p.db };
 		int32_t q[3][4];
+		const Bc6hSignedUnq sk = bc6h_signed_unq(p.epb);
+		// signed, :487-518 in one form for transformed and untransformed modes: value = sext_epb(base' + sext_w(field)) with
+		// (base', w) = (base, delta width) or (0, epb) -- the wrap to epb bits and the sign extension are one v_bfe_i32
+		int32_t base_t[3];
+		uint32_t width_t[3];
+		if (SIGNED) {
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				base_t[c] = delta[c] ? sbfe(ep[c][0], 0, p.epb) : 0;
+				width_t[c] = delta[c] ? delta[c] : p.epb;
+			}
+		}
 		// :487-518 sign extension and delta transform, :520-533 unquantisation
 		auto endpoint = [&](int c, int e) {
-			const int32_t e0 = SIGNED ? sbfe(ep[c][0], 0, p.epb) : (int32_t)ep[c][0];
-			int32_t v = e0;
-			if (e > 0) {
-				const uint32_t t = ubfe((uint32_t)(e0 + sbfe(ep[c][e], 0, delta[c])), 0, p.epb);
-				const uint32_t raw = delta[c] ? t : ep[c][e];
-				v = SIGNED ? sbfe(raw, 0, p.epb) : (int32_t)raw;
+			int32_t v;
+			if (SIGNED) {
+				v = e == 0 ? sbfe(ep[c][0], 0, p.epb) : sbfe((uint32_t)(base_t[c] + sbfe(ep[c][e], 0, width_t[c])), 0, p.epb);
+			} else {
+				v = (int32_t)ep[c][0];
+				if (e > 0) {
+					const uint32_t t = ubfe((uint32_t)(v + sbfe(ep[c][e], 0, delta[c])), 0, p.epb);
+					v = (int32_t)(delta[c] ? t : ep[c][e]);
+				}
 			}
 #if defined(DETEXHIP_EXP_NO_UNQUANTIZE)	// measurement build (WRONG results): upper bound of a table-driven unquantisation
 			q[c][e] = v;
 #else
-			q[c][e] = SIGNED ? bc6h_unquantize_signed(v, p.epb) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
+			q[c][e] = SIGNED ? bc6h_unquantize_signed(v, sk) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
 #endif
 		};
 #pragma unroll
