@@ -296,20 +296,27 @@ DH int32_t bc6h_unquantize_unsigned(uint32_t x, uint32_t epb) {
 }
 // decompress-bptc-float.c:65-86: sign(x) * U(|x|) with U(0) = 0, U(a) = 0x7FFF for a >= lim = 2^(epb-1) - 1, else
 // ((a << 15) + 0x4000) >> (epb - 1).  Both terms of that middle case are multiples of 2^(epb-1) (epb <= 15 there), so it is
-// (2a + 1) << (15 - epb) exactly, and with the sign:  (2x + sign(x)) << (15 - epb), sign(x) = v_med3_i32(x, -1, 1) -- which is also
-// right at x = 0.  |x| >= lim as one unsigned compare of x + lim - 1 against 2 lim - 1.  Eight instructions where the
-// literal form (absolute value, three compares, three selects, negate) took twelve.
-struct Bc6hSignedUnq { uint32_t shift, lim_m1, lim2_m1; bool passthrough; };	// per block: from epb
+// (2a + 1) << (15 - epb) exactly, and with the sign:  (2x + sign(x)) << (15 - epb), sign(x) = v_med3_i32(x, -1, 1) -- which is
+// also right at x = 0.  |x| >= lim as one unsigned compare of x + lim - 1 against 2 lim - 1.  The 16-bit mode (epb = 16:
+// the value passes through, :66) is the same expression with sign() replaced by 0, one shift less and a limit no value
+// reaches.  The result is delivered TIMES FOUR (two more shift positions), which is what the texel loop's rows want.
+// Seven instructions where the literal form (absolute value, three compares, four selects, negate) took thirteen.
+struct Bc6hSignedUnq { int32_t unit, neg_unit; uint32_t shift, lim_m1, lim2_m1; };	// per block: from epb
 DH Bc6hSignedUnq bc6h_signed_unq(uint32_t epb) {
 	const uint32_t lim = (1u << ((epb - 1u) & 31u)) - 1u;
-	return Bc6hSignedUnq{ (15u - epb) & 31u, lim - 1u, 2u * lim - 1u, epb >= 16u };
+	const bool pass = epb >= 16u;
+	return Bc6hSignedUnq{ pass ? 0 : 1, pass ? 0 : -1, pass ? 1u : 17u - epb, pass ? 40000u : lim - 1u, pass ? 0x7FFFFFFFu : 2u * lim - 1u };
 }
-DH int32_t bc6h_unquantize_signed(int32_t x, const Bc6hSignedUnq &k) {
-	const int32_t sign = sign_of(x);
+#if defined(__HIPCC__)
+DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { int32_t r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
+#else
+DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
+#endif
+DH int32_t bc6h_unquantize_signed_x4(int32_t x, const Bc6hSignedUnq &k) {
+	const int32_t sign = bc6h_clamp_sign(x, k.neg_unit, k.unit);
 	// (both sides through opaque(): evaluated unconditionally and chosen by a select -- the compiler otherwise branches)
-	const uint32_t mid = opaque((uint32_t)(2 * x + sign) << k.shift), top = opaque((uint32_t)__mul24(sign, 0x7FFF));
-	const int32_t u = (int32_t)((uint32_t)x + k.lim_m1 >= k.lim2_m1 ? top : mid);
-	return k.passthrough ? x : u;
+	const uint32_t mid = opaque((uint32_t)(2 * x + sign) << k.shift), top = opaque((uint32_t)__mul24(sign, 4 * 0x7FFF));
+	return (int32_t)((uint32_t)x + k.lim_m1 >= k.lim2_m1 ? top : mid);
 }
 
 // both signed 16-bit lanes: two's complement -> sign-magnitude half of trunc(v * 31 / 32) (decompress-bptc-float.c:576-609)
@@ -383,11 +390,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 					v = (int32_t)(delta[c] ? t : ep[c][e]);
 				}
 			}
-#if defined(DETEXHIP_EXP_NO_UNQUANTIZE)	// measurement build (WRONG results): upper bound of a table-driven unquantisation
-			q[c][e] = v;
-#else
-			q[c][e] = SIGNED ? bc6h_unquantize_signed(v, sk) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);
-#endif
+			q[c][e] = SIGNED ? bc6h_unquantize_signed_x4(v, sk) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);	// signed: 4 * value
 		};
 #pragma unroll
 		for (int c = 0; c < 3; c++) { endpoint(c, 0); endpoint(c, 1); q[c][2] = 0; q[c][3] = 0; }
@@ -416,16 +419,16 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		for (int s = 0; s < 2; s++) {
 			if (s == 1 && !wave_two) break;
 			uint4 ra; uint2 rb;
-			// signed: everything times 4, so that the 16 result bits of (base + w * diff) >> 6 are bytes 1-2 of the sum
+			// signed: q[] holds 4 * value, so that the 16 result bits of (base + w * diff) >> 6 are bytes 1-2 of the sum
 			// (|sum| < 2^23, 4 * |diff| < 2^19: still inside v_mad_i32_i24's operands) and one v_perm_b32 both drops the
 			// six fraction bits and packs two channels -- no shifts in the texel loop
-			constexpr int kScale = SIGNED ? 4 : 1;
-			ra.x = (uint32_t)(q[0][2 * s] * (64 * kScale) + 32 * kScale);
-			ra.y = (uint32_t)(q[1][2 * s] * (64 * kScale) + 32 * kScale);
-			ra.z = (uint32_t)(q[2][2 * s] * (64 * kScale) + 32 * kScale);
-			ra.w = (uint32_t)((q[0][2 * s + 1] - q[0][2 * s]) * kScale);
-			rb.x = (uint32_t)((q[1][2 * s + 1] - q[1][2 * s]) * kScale);
-			rb.y = (uint32_t)((q[2][2 * s + 1] - q[2][2 * s]) * kScale);
+			constexpr int kRound = SIGNED ? 128 : 32;
+			ra.x = (uint32_t)(q[0][2 * s] * 64 + kRound);
+			ra.y = (uint32_t)(q[1][2 * s] * 64 + kRound);
+			ra.z = (uint32_t)(q[2][2 * s] * 64 + kRound);
+			ra.w = (uint32_t)(q[0][2 * s + 1] - q[0][2 * s]);
+			rb.x = (uint32_t)(q[1][2 * s + 1] - q[1][2 * s]);
+			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
 			lane.put(s, ra, rb);
 		}
 		const uint32_t p12 = pe.pmask12, p11 = p12 >> 1;
