@@ -1,5 +1,5 @@
 #!/bin/bash
-# measurement builds of libdetexhip (never shipped): bash tools/build_exp_libs.sh nostore nocompute pad8192 ...
+# measurement builds of libdetexhip (never shipped): bash tools/build_exp_libs.sh nostore nocompute pad8192 sgprconst rgtc1g2 planarinlane bc7stage ...
 set -e
 cd "$(dirname "$0")/.."
 for v in "$@"; do
@@ -11,6 +11,10 @@ for v in "$@"; do
     nonpersistent) D=-DDETEXHIP_EXP_BC7_NONPERSISTENT ;;
     plain) D=-DDETEXHIP_EXP_BC7_PLAIN ;;
     plain_nonpersistent) D="-DDETEXHIP_EXP_BC7_PLAIN -DDETEXHIP_EXP_BC7_NONPERSISTENT" ;;
+    sgprconst) D=-DDETEXHIP_EXP_SGPR_CONST ;;                 # v_bitop3 masks left in SGPRs (BC7 / BC6H)
+    rgtc1g*) D=-DDETEXHIP_EXP_RGTC1_GROUP=${v#rgtc1g} ;;      # RGTC1 blocks per lane (1 = the one-block kernel)
+    planarinlane) D=-DDETEXHIP_EXP_PLANAR_IN_LANE ;;          # ETC2 planar blocks always decoded in their own lanes
+    bc7stage) D=-DDETEXHIP_EXP_BC7_SEPARATE_STAGE ;;          # block-major BC7 with the separate 17 KiB staging array
     *) D="$EXP_DEFS" ;;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $D -Wall -Wno-unused-function \
