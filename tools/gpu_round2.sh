@@ -15,7 +15,9 @@ timeout 300 python bench.py --size 16384 --steps 50 --no-cpu --no-extras > $OUT/
 timeout 300 python bench.py --format BPTC_FLOAT --size 32768 --band-height 4096 --steps 100 --warmup 300 --no-cpu --no-extras > $OUT/bench_bc6h_32768x4096.json 2>>$OUT/bench.err
 timeout 300 python bench.py --size 32768 --band-height 8192 --steps 50 --no-cpu --no-extras > $OUT/bench_bc1_32768x8192.json 2>>$OUT/bench.err
 for f in bench_16384 bench_bc6h_32768x4096 bench_bc1_32768x8192; do python -c "import json;d=json.load(open('$OUT/$f.json'));print('$f', d['value'], 'Gpixel/s', d['roofline']['launch_us'], 'us', d['roofline']['frac'])"; done
-echo "== epilogue targets"; for spec in BC1:BGRA8 BC1:RGB8 RGTC1:BGRX8 EAC_RG11:RGB8 BPTC_FLOAT:FLOAT_BGRX16 BPTC_FLOAT:BGRX8; do f=${spec%%:*}; t=${spec##*:}; timeout 200 python bench.py --format $f --target $t --no-cpu --no-extras > $OUT/bench_${f}_$t.json 2>>$OUT/bench.err; python -c "import json;d=json.load(open('$OUT/bench_${f}_$t.json'));print('$f -> $t', d['roofline']['launch_us'], 'us', d['roofline']['frac'], d.get('verified_bit_exact_rows'))"; done
+echo "== small-pixel formats at 16384^2 (their 8192^2 launches are 15-30 us: ramp and tail are a visible share)"
+timeout 300 python tools/gpu_time.py RGTC1,SIGNED_RGTC1,RGTC2,EAC_R11,EAC_SIGNED_R11 U linear 16384 2>>$OUT/bench.err | tee $OUT/small_formats_16384.jsonl | cut -c1-140
+echo "== epilogue targets"; for spec in BC1:BGRA8 BC1:RGB8 RGTC1:BGRX8 EAC_RG11:RGB8 BPTC_FLOAT:FLOAT_BGRX16 BPTC_FLOAT:BGRX8 BPTC_FLOAT:RGB8; do f=${spec%%:*}; t=${spec##*:}; timeout 200 python bench.py --format $f --target $t --no-cpu --no-extras > $OUT/bench_${f}_$t.json 2>>$OUT/bench.err; python -c "import json;d=json.load(open('$OUT/bench_${f}_$t.json'));print('$f -> $t', d['roofline']['launch_us'], 'us', d['roofline']['frac'], d.get('verified_bit_exact_rows'))"; done
 echo "== N=2 code path over gloo on one GPU (plumbing, not a measurement)"
 DETEX_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_n2_gloo_one_gpu.json 2>> $OUT/bench.err; cut -c1-300 $OUT/bench_n2_gloo_one_gpu.json
 echo "== BC7 / BC6H old-vs-new (A/B build)"
