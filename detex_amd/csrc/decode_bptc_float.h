@@ -334,13 +334,20 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626
+	// A block that fails (reserved mode, or a mode outside mode_mask) is decoded as the ALL-ZERO block instead of leaving
+	// early: that is a mode-0 block whose endpoints are all 0, and it decodes to sixteen zero pixels on this very path -- so
+	// the caller's zero-fill of a failed block (32 moves that nearly every wave of a random stream executes: one block in
+	// sixteen carries a reserved mode) is not needed (kernels.h: decode_word)
+	static constexpr bool kZeroOnFailure = true;
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t, uint32_t (&d)[32]) {
-		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
 		// :23-33: 2-bit codes 00/01 = modes 0/1, otherwise a 5-bit code; 10011,10111,11011,11111 reserved
 		const uint32_t low2 = blk.x & 3u, low5 = blk.x & 0x1Fu;
-		const uint32_t mode = low2 < 2u ? low2 : (low2 == 2u ? 2u + (low5 >> 2) : 10u + (low5 >> 2));
-		if (mode > 13u) return false;
-		if (CHECKED && !(mode_mask & (1u << mode))) return false;
+		const uint32_t coded = low2 < 2u ? low2 : (low2 == 2u ? 2u + (low5 >> 2) : 10u + (low5 >> 2));
+		const bool valid = coded <= 13u && (!CHECKED || (mode_mask & (1u << (coded & 31u))) != 0u);
+		const uint32_t keep = cond_to_mask(valid);
+		blk.x &= keep; blk.y &= keep; blk.z &= keep; blk.w &= keep;
+		const uint32_t mode = coded & keep;
+		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
 		uint32_t ep[3][4] = {};
 		Bc6hParams p;
 		if (!SWITCH_SCATTER) p = bc6h_scatter_generic(b, mode, ep);
@@ -469,7 +476,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 				d[2 * i + 1] = h[2];				// X = 0
 			}
 		}
-		return true;
+		return valid;
 	}
 };
 using DecBPTCFloat = DecBPTCFloatT<false>;

@@ -33,6 +33,10 @@ template <class Dec> struct PersistentTiles<Dec, std::enable_if_t<Dec::kPersiste
 template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
 template <class Dec> struct WavesPerSimd<Dec, std::enable_if_t<(Dec::kWavesPerSimd > 0)>> { static constexpr int value = Dec::kWavesPerSimd; };
 
+// decoders that deliver sixteen zero pixels themselves when they return false (Dec::kZeroOnFailure)
+template <class Dec, class = void> struct ZeroOnFailure { static constexpr bool value = false; };
+template <class Dec> struct ZeroOnFailure<Dec, std::enable_if_t<Dec::kZeroOnFailure>> { static constexpr bool value = true; };
+
 // decoders whose per-lane LDS rows double as the staging area of the block-major exchange (Dec::kOwnStage, Dec::stage_slot)
 template <class Dec, class = void> struct OwnStage { static constexpr bool value = false; };
 template <class Dec> struct OwnStage<Dec, std::enable_if_t<Dec::kOwnStage>> { static constexpr bool value = true; };
@@ -295,7 +299,11 @@ DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint3
 	const bool ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
 #endif
 	EpilogueOf<Dec, EPI>::apply(d, o);
-	if (!ok) {	// texture.c:125-128: a failed block is zero-filled in the TARGET format (not "converted zeros": X / alpha stay 0)
+	// texture.c:125-128: a failed block is zero-filled in the TARGET format (not "converted zeros": X / alpha stay 0).
+	// Decoders that already deliver zeros for a failed block (Dec::kZeroOnFailure) skip this when the epilogue maps zeros to
+	// zeros (native target, channel swaps).
+	constexpr bool already_zero = ZeroOnFailure<Dec>::value && (EPI == kEpiNone || EPI == kEpiSwapRB16 || EPI == kEpiSwapRB8);
+	if (!already_zero && !ok) {
 #pragma unroll
 		for (int k = 0; k < 4 * EpilogueOf<Dec, EPI>::kRowDwords; k++) o[k] = 0u;
 	}

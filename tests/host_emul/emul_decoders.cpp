@@ -4,6 +4,7 @@
 // this GPU-less container.  Not part of the product; libdetexhip.so never contains this.
 #define DETEXHIP_HOST_EMULATION 1
 #include <string.h>
+#include <type_traits>
 #include "dev_common.h"
 #include "decode_s3tc_rgtc.h"
 #include "decode_etc_eac.h"
@@ -16,15 +17,20 @@ template <int BYTES> struct Word;
 template <> struct Word<8> { typedef uint2 type; };
 template <> struct Word<16> { typedef uint4 type; };
 
+// decoders that promise sixteen zero pixels for a failed block (Dec::kZeroOnFailure) are taken at their word here, so the
+// emulation tests check the promise
+template <class Dec, class = void> struct ZeroOnFailure { static constexpr bool value = false; };
+template <class Dec> struct ZeroOnFailure<Dec, typename std::enable_if<Dec::kZeroOnFailure>::type> { static constexpr bool value = true; };
+
 template <class Dec> static void run(const uint8_t *in, long n, uint32_t mode_mask, uint32_t flags, int checked, uint8_t *out, uint8_t *ok) {
 	constexpr int P = Dec::kPixelBytes;
 	for (long i = 0; i < n; i++) {
 		typename Word<Dec::kBlockBytes>::type blk;
 		memcpy(&blk, in + i * Dec::kBlockBytes, Dec::kBlockBytes);
 		uint32_t d[4 * P];
-		memset(d, 0, sizeof d);
+		memset(d, 0xA5, sizeof d);
 		const bool r = checked ? Dec::template decode<true>(blk, mode_mask, flags, d) : Dec::template decode<false>(blk, mode_mask, flags, d);
-		if (!r) memset(d, 0, sizeof d);
+		if (!r && !ZeroOnFailure<Dec>::value) memset(d, 0, sizeof d);
 		memcpy(out + i * 16 * P, d, 16 * P);
 		ok[i] = r;
 	}
