@@ -177,12 +177,30 @@ __constant__ uint32_t kBc7Gather[4] = { 0x07050301u, 0x01050307u, 0x03050701u, 0
 // subset rows first (row s of lane l at 4096*s + 16*l: bits 12-13 of a lane's base are clear, so the row address
 // of a texel is bitop3((pword pre-shifted) & 0x3000 | base)); the fourth 4 KiB slot and what follows hold the
 // workgroup tables and the per-lane block dwords.
-#if defined(__HIPCC__)
-struct Bc7Lds {
-	uint4 subset[3][256];			// per-lane blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba}
+// the workgroup tables as ONE constant image, so that the copy into LDS is a single 16-byte load and a single
+// ds_write_b128 per thread (224 of the 256 threads) instead of four dword loads and stores each
+struct alignas(16) Bc7Tables {
 	Bc7Rec rec[kBc7Recs];
 	uint32_t gather[4];
 	Bc7PartEntry part[kBc7PartEntries];
+	uint32_t pad[2];
+};
+static_assert(sizeof(Bc7Tables) % 16 == 0 && sizeof(Bc7Tables) / 16 <= 256, "one 16-byte vector per thread");
+constexpr Bc7Tables bc7_tables() {
+	Bc7Tables t = {};
+	const Bc7RecTable r = bc7_rec_table();
+	const Bc7PartTable p = bc7_part_table();
+	for (int k = 0; k < kBc7Recs; k++) t.rec[k] = r.r[k];
+	for (int k = 0; k < kBc7PartEntries; k++) t.part[k] = p.e[k];
+	t.gather[0] = 0x07050301u; t.gather[1] = 0x01050307u; t.gather[2] = 0x03050701u; t.gather[3] = 0x05070301u;	// = kBc7Gather
+	return t;
+}
+__constant__ Bc7Tables kBc7Tables = bc7_tables();
+
+#if defined(__HIPCC__)
+struct Bc7Lds {
+	uint4 subset[3][256];			// per-lane blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba}
+	Bc7Tables t;
 	// per-lane block dwords, LAST member: fields that start near the end of the block also read "rows" 4 and 5,
 	// i.e. up to 2 KiB past this array -- LDS reads beyond the allocation return 0 rather than faulting, and whatever
 	// they return stands for bits beyond 127, which no field or index ever consumes
@@ -195,22 +213,13 @@ struct Bc7Lds {
 static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU");
 #endif
 DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
+// (Requesting the kernel's first block between the table load and its LDS store -- so that the block travels during the
+// barrier -- was measured too: the compiler issues the block load first either way, and then the barrier waits for the
+// slowest wave's HBM round trip: stream C 49.4 vs 48.3 us.  The block is loaded after the barrier.)
 DH void bc7_prepare() {
-	Bc7Lds &s = bc7_lds();
-	const uint32_t k = threadIdx.x;
-	{
-		constexpr uint32_t kWords = sizeof(Bc7RecTable) / 4u;
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc7RecTable);
-		uint32_t *dst = reinterpret_cast<uint32_t *>(s.rec);
-		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
-	}
-	{
-		constexpr uint32_t kWords = sizeof(Bc7PartTable) / 4u;
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc7PartTable);
-		uint32_t *dst = reinterpret_cast<uint32_t *>(s.part);
-		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
-	}
-	if (k < 4u) s.gather[k] = kBc7Gather[k];
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	if (threadIdx.x < sizeof(Bc7Tables) / 16u)
+		reinterpret_cast<u32x4 *>(&bc7_lds().t)[threadIdx.x] = reinterpret_cast<const u32x4 *>(&kBc7Tables)[threadIdx.x];
 	__syncthreads();
 }
 #endif
@@ -259,12 +268,12 @@ struct Bc7Lane {
 	static DH const Bc7Rec &rec(uint32_t r) {
 		uint32_t off = r * (uint32_t)sizeof(Bc7Rec);
 		asm("" : "+v"(off));	// one opaque byte offset: the fields then come as immediate offsets of a few wide LDS reads
-		return *reinterpret_cast<const Bc7Rec *>(reinterpret_cast<const char *>(bc7_lds().rec) + off);
+		return *reinterpret_cast<const Bc7Rec *>(reinterpret_cast<const char *>(bc7_lds().t.rec) + off);
 	}
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) {
-		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().part) + byte_offset);
+		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().t.part) + byte_offset);
 	}
-	static DH uint32_t gather(uint32_t rot) { return bc7_lds().gather[rot]; }
+	static DH uint32_t gather(uint32_t rot) { return bc7_lds().t.gather[rot]; }
 #else
 	uint32_t bits[6];
 	uint4 subset[3];
@@ -417,11 +426,18 @@ template <bool UNIFORM> struct DecBPTCT {
 	// +2.5 % HBM traffic); 80 VGPRs (no spill) 57.9 / 50.8.  LDS (<= 20 KiB per workgroup) would admit eight workgroups.
 	static constexpr int kWavesPerSimd = 6;
 #endif
-#if defined(DETEXHIP_EXP_BC7_NONPERSISTENT)	// measurement build
-	static constexpr bool kPersistent = false;
+	// One workgroup per tile, like every other decoder.  A persistent grid (workgroups looping over tiles, the 3.6 KiB of
+	// tables copied once per resident workgroup, the next tile's block prefetched) was the better choice while the tables
+	// were 7.5 KiB (58.8 vs 62.0 us, stream U); with today's tables it is the worse one -- same run, 8192^2, streams U / C:
+	// persistent 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (kernels.h keeps the persistent path for
+	// -DDETEXHIP_EXP_BC7_PERSISTENT).
+	// The block-major kernel keeps the persistent grid: stream U 61.6 vs 66.4 us, stream C 52.1 vs 49.3.
+#if defined(DETEXHIP_EXP_BC7_PERSISTENT)	// measurement build
+	static constexpr bool kPersistent = true;
 #else
-	static constexpr bool kPersistent = true;	// sizeable LDS tables: workgroups loop over tiles (kernels.h)
+	static constexpr bool kPersistent = false;
 #endif
+	static constexpr bool kPersistentBlocks = true;
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
 #if !defined(DETEXHIP_EXP_BC7_SEPARATE_STAGE)

@@ -122,8 +122,8 @@ template <class K> uint32_t resident_workgroups(K kernel) {
 // 5x 58.5 / 51.1, 9x (one tile each, the table copy paid per tile) 62.0 / 53.5: a second round lets the dispatcher even
 // out the CUs, more rounds only add table copies.  Decoders without sizeable tables are 1-20 % SLOWER on a persistent
 // grid than with one workgroup per tile (measured for all of them), so only BC7 uses one.
-template <class Dec, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
-	if constexpr (PersistentTiles<Dec>::value) {
+template <class Dec, bool BLOCK_MAJOR = false, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
+	if constexpr (BLOCK_MAJOR ? PersistentBlocks<Dec>::value : PersistentTiles<Dec>::value) {
 		const uint32_t grid = 2u * resident_workgroups(kernel);
 		return tiles < grid ? tiles : grid;
 	}
@@ -181,11 +181,11 @@ template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 	uint8_t *px = static_cast<uint8_t *>(a.pixels);
 	if (a.checked) {
 		auto kernel = decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>;
-		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec, true>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	} else {
 		auto kernel = decode_blocks<Dec, EPI, false>;
-		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec, true>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	}
 	return hipGetLastError();

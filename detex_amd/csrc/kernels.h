@@ -28,6 +28,9 @@ namespace detexhip {
 // over tiles of 256 blocks, so the table copy at kernel entry is paid once per resident workgroup
 template <class Dec, class = void> struct PersistentTiles { static constexpr bool value = false; };
 template <class Dec> struct PersistentTiles<Dec, std::enable_if_t<Dec::kPersistent>> { static constexpr bool value = true; };
+// the same choice for the block-major kernel (Dec::kPersistentBlocks)
+template <class Dec, class = void> struct PersistentBlocks { static constexpr bool value = false; };
+template <class Dec> struct PersistentBlocks<Dec, std::enable_if_t<Dec::kPersistentBlocks>> { static constexpr bool value = true; };
 
 // waves per SIMD the register allocation must leave room for (Dec::kWavesPerSimd; default: no constraint)
 template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
@@ -330,8 +333,8 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	// First block: persistent grids request it BEFORE the table copy and wait for it after the barrier (the copy is 7.5 KiB
-	// there); one-tile workgroups load it after the barrier, as in round 1 -- requesting it earlier made the workgroup's
+	// First block: persistent grids (measurement builds) request it BEFORE the table copy and wait for it after the barrier;
+	// one-tile workgroups load it after the barrier, as in round 1 -- requesting it earlier made the workgroup's
 	// barrier wait for its slowest wave's HBM load (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 against the round-1
 	// library in the same run).  Loads are unconditional, with the index clamped into the stream: a load under a branch
 	// makes the compiler wait for it at the end of the branch.
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
-	const uint32_t n_tiles = PersistentTiles<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
+	const uint32_t n_tiles = PersistentBlocks<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
 	// (requesting the next tile's block ahead, as decode_linear does, measured no gain here: 63.6-64.0 vs 62.4-63.0 us on BC7)
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t i = tile * 256u + threadIdx.x;
