@@ -13,6 +13,7 @@
 //
 // Reference quirk reproduced: in mode 12 block bit 63 (b0[11]) reads as 0.
 #pragma once
+#include <stddef.h>
 #include "dev_common.h"
 #include "bptc_common.h"
 
@@ -196,17 +197,22 @@ struct Bc6hLds {
 	Bc6hPartEntry part[33];
 	Bc6hModeWords modes[14];
 };
+// both workgroup tables as one constant image: the copy is one 16-byte load and one ds_write_b128 for 80 threads
+struct alignas(16) Bc6hTables { Bc6hPartEntry part[33]; Bc6hModeWords modes[14]; };
+static_assert(sizeof(Bc6hTables) == 33 * 32 + 14 * 16 && offsetof(Bc6hLds, modes) - offsetof(Bc6hLds, part) == 33 * 32, "image = LDS layout");
+constexpr Bc6hTables bc6h_tables() {
+	Bc6hTables t = {};
+	const Bc6hPartTable p = bc6h_part_table();
+	for (int k = 0; k < 33; k++) t.part[k] = p.e[k];
+	for (int k = 0; k < 14; k++) t.modes[k] = bc6h_derive(k).w;
+	return t;
+}
+__constant__ Bc6hTables kBc6hTables = bc6h_tables();
 DH Bc6hLds &bc6h_lds() { __shared__ __attribute__((aligned(8192))) Bc6hLds s; return s; }
 DH void bc6h_prepare() {
-	Bc6hLds &s = bc6h_lds();
-	const uint32_t k = threadIdx.x;
-	if (k >= 200u && k < 214u) s.modes[k - 200u] = kBc6hModeWords[k - 200u];
-	{
-		constexpr uint32_t kWords = sizeof(Bc6hPartTable) / 4u;
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(&kBc6hPartTable);
-		uint32_t *dst = reinterpret_cast<uint32_t *>(s.part);
-		for (uint32_t w = k; w < kWords; w += 256u) dst[w] = src[w];
-	}
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	if (threadIdx.x < sizeof(Bc6hTables) / 16u)
+		reinterpret_cast<u32x4 *>(bc6h_lds().part)[threadIdx.x] = reinterpret_cast<const u32x4 *>(&kBc6hTables)[threadIdx.x];
 	__syncthreads();
 }
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_lds().modes[mode]; }
