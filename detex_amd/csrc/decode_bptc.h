@@ -437,7 +437,11 @@ template <bool UNIFORM> struct DecBPTCT {
 #else
 	static constexpr bool kPersistent = false;
 #endif
+#if defined(DETEXHIP_EXP_BC7_BLOCKS_ONE_TILE)	// measurement build
+	static constexpr bool kPersistentBlocks = false;
+#else
 	static constexpr bool kPersistentBlocks = true;
+#endif
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
 #if !defined(DETEXHIP_EXP_BC7_SEPARATE_STAGE)
