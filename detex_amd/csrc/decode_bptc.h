@@ -431,16 +431,12 @@ template <bool UNIFORM> struct DecBPTCT {
 	// were 7.5 KiB (58.8 vs 62.0 us, stream U); with today's tables it is the worse one -- same run, 8192^2, streams U / C:
 	// persistent 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (kernels.h keeps the persistent path for
 	// -DDETEXHIP_EXP_BC7_PERSISTENT).
-	// The block-major kernel keeps the persistent grid: stream U 61.6 vs 66.4 us, stream C 52.1 vs 49.3.
+	// The block-major kernel likewise (same run, U / M / C: persistent 62.5-63.3 / 63.8-64.7 / 52.0, one tile per
+	// workgroup 64.5 / 66.1 / 47.4: real content is the C case).
 #if defined(DETEXHIP_EXP_BC7_PERSISTENT)	// measurement build
-	static constexpr bool kPersistent = true;
+	static constexpr bool kPersistent = true, kPersistentBlocks = true;
 #else
-	static constexpr bool kPersistent = false;
-#endif
-#if defined(DETEXHIP_EXP_BC7_BLOCKS_ONE_TILE)	// measurement build
-	static constexpr bool kPersistentBlocks = false;
-#else
-	static constexpr bool kPersistentBlocks = true;
+	static constexpr bool kPersistent = false, kPersistentBlocks = false;
 #endif
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }

@@ -8,10 +8,9 @@ for v in "$@"; do
     nocompute) D=-DDETEXHIP_EXP_NOCOMPUTE ;;
     pad*) D=-DDETEXHIP_EXP_LDS_PAD=${v#pad} ;;
     waves*) D=-DDETEXHIP_EXP_BC7_WAVES=${v#waves} ;;
-    persistent) D=-DDETEXHIP_EXP_BC7_PERSISTENT ;;             # BC7 on the persistent grid of round 2's first half
+    persistent) D=-DDETEXHIP_EXP_BC7_PERSISTENT ;;             # BC7 (linear and block-major) on the persistent grid of round 2's first half
     plain) D=-DDETEXHIP_EXP_BC7_PLAIN ;;
     plain_persistent) D="-DDETEXHIP_EXP_BC7_PLAIN -DDETEXHIP_EXP_BC7_PERSISTENT" ;;
-    blocksonetile) D=-DDETEXHIP_EXP_BC7_BLOCKS_ONE_TILE ;;     # block-major BC7 with one workgroup per tile
     sgprconst) D=-DDETEXHIP_EXP_SGPR_CONST ;;                 # v_bitop3 masks left in SGPRs (BC7 / BC6H)
     rgtc1g*) D=-DDETEXHIP_EXP_RGTC1_GROUP=${v#rgtc1g} ;;      # RGTC1 blocks per lane (1 = the one-block kernel)
     planarinlane) D=-DDETEXHIP_EXP_PLANAR_IN_LANE ;;          # ETC2 planar blocks always decoded in their own lanes
