@@ -124,6 +124,9 @@ template <class K> uint32_t resident_workgroups(K kernel) {
 // grid than with one workgroup per tile (measured for all of them), so only BC7 uses one.
 template <class Dec, bool BLOCK_MAJOR = false, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
 	if constexpr (BLOCK_MAJOR ? PersistentBlocks<Dec>::value : PersistentTiles<Dec>::value) {
+		// (measurement builds only: DETEXHIP_TILES_PER_WORKGROUP=n makes the grid tiles / n instead)
+		static const uint32_t tiles_per_wg = [] { const char *e = getenv("DETEXHIP_TILES_PER_WORKGROUP"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 0u; }();
+		if (tiles_per_wg) return (tiles + tiles_per_wg - 1u) / tiles_per_wg;
 		const uint32_t grid = 2u * resident_workgroups(kernel);
 		return tiles < grid ? tiles : grid;
 	}
