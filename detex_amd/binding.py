@@ -131,15 +131,17 @@ def decompress_blocks_device(fmt, blocks, n_blocks, mode_mask=F.MODE_MASK_ALL, f
     return out, ok
 
 
-def mode_histogram_device(fmt, blocks, n_blocks, hist=None, stream=None):
-    """detexhipModeHistogramDevice: 16 bins (uint32) of the reference's detexGetMode<FMT> values."""
+def mode_histogram_device(fmt, blocks, n_blocks, hist=None, stream=None, accumulate=False):
+    """detexhipModeHistogramDevice: 16 bins (uint32) of the reference's detexGetMode<FMT> values
+    (accumulate=True: detexhipModeHistogramAccumulateDevice, added to `hist` instead of replacing it)."""
     import torch
     lib = load()
     if hist is None:
         hist = torch.zeros(16, dtype=torch.int32, device=blocks.device)
-    lib.detexhipModeHistogramDevice.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
-    _check(lib.detexhipModeHistogramDevice(fmt.texture_format, blocks.data_ptr(), n_blocks, hist.data_ptr(), _stream_handle(stream)),
-           "detexhipModeHistogramDevice")
+    name = "detexhipModeHistogramAccumulateDevice" if accumulate else "detexhipModeHistogramDevice"
+    fn = getattr(lib, name)
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    _check(fn(fmt.texture_format, blocks.data_ptr(), n_blocks, hist.data_ptr(), _stream_handle(stream)), name)
     return hist
 
 

@@ -220,8 +220,8 @@ template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
 }
 
 // 8f-4: block-mode histogram (kernels_extra.h)
-template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks, size_t n, uint32_t *hist, hipStream_t stream) {
-	hipError_t e = hipMemsetAsync(hist, 0, 16 * sizeof(uint32_t), stream);
+template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first) {
+	hipError_t e = zero_first ? hipMemsetAsync(hist, 0, 16 * sizeof(uint32_t), stream) : hipSuccess;
 	if (e != hipSuccess || n == 0) return e;
 	// 1024-lane workgroups, eight loads in flight per lane; every further workgroup adds serialised global atomics at the end
 	// (kernels_extra.h).  Measured, 4 Mi / 16 Mi blocks, us per call incl. the memset: BC7 grid 96: 15.3, 128: 14.0 / 40.5,
@@ -242,7 +242,7 @@ struct FormatEntry {
 	hipError_t (*linear)(const Geometry &);
 	hipError_t (*blocks)(const BatchArgs &);
 	hipError_t (*levels)(LevelsArgs &);
-	hipError_t (*histogram)(const void *, size_t, uint32_t *, hipStream_t);
+	hipError_t (*histogram)(const void *, size_t, uint32_t *, hipStream_t, bool);
 	const char *kernel_name;
 };
 
@@ -543,15 +543,23 @@ extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, con
 }
 
 // 8f-4 device tier
+static int mode_histogram_device(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist, void *stream, bool zero_first);
 extern "C" int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist,
 		void *stream) {
+	return mode_histogram_device(texture_format, d_blocks, n_blocks, d_hist, stream, true);
+}
+extern "C" int detexhipModeHistogramAccumulateDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist,
+		void *stream) {
+	return mode_histogram_device(texture_format, d_blocks, n_blocks, d_hist, stream, false);
+}
+static int mode_histogram_device(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist, void *stream, bool zero_first) {
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("detexhipModeHistogramDevice: 0x%08X is not a block-compressed format of this library", texture_format); return 1; }
 	if (n_blocks > 0xFFFFFF00ull || !d_hist || reinterpret_cast<uintptr_t>(d_blocks) % detexGetCompressedBlockSize(texture_format) != 0) {
 		detexSetErrorMessage("detexhipModeHistogramDevice: bad arguments (d_hist NULL, d_blocks not block-aligned, or too many blocks)");
 		return 1;
 	}
-	hipError_t e = f->histogram(d_blocks, n_blocks, d_hist, static_cast<hipStream_t>(stream));
+	hipError_t e = f->histogram(d_blocks, n_blocks, d_hist, static_cast<hipStream_t>(stream), zero_first);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
 }

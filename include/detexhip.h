@@ -145,6 +145,10 @@ DETEXHIP_API bool detexhipHostDecompressTextureTiled(const detexTexture *texture
  * d_hist: 16 uint32_t, zeroed by the call. */
 DETEXHIP_API int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
 	uint32_t *d_hist, void *stream);
+/* The same count ADDED to d_hist (not zeroed): one histogram over several textures or the levels of a mip chain; a single
+ * kernel launch, where the call above is a 64-byte memset plus the kernel. */
+DETEXHIP_API int detexhipModeHistogramAccumulateDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
+	uint32_t *d_hist, void *stream);
 DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,
 	uint32_t histogram[16]);
 

@@ -250,3 +250,12 @@ def test_mode_histogram(fmt, torch_cuda, oracle):
     assert lib.detexhipModeHistogram(fmt.texture_format, ol._ptr(np.ascontiguousarray(blocks)), len(blocks), hist.ctypes.data)
     assert np.array_equal(hist, want), (fmt.name, hist, want)
     assert hist.sum() == len(blocks)
+    # the accumulating device entry: two parts of the stream added into one histogram that starts non-zero
+    d = torch.from_numpy(np.ascontiguousarray(blocks).reshape(-1)).cuda()
+    split = (len(blocks) // 3) * fmt.block_bytes
+    start = torch.arange(16, dtype=torch.int32, device="cuda")
+    acc = start.clone()
+    binding.mode_histogram_device(fmt, d[:split], split // fmt.block_bytes, hist=acc, accumulate=True)
+    binding.mode_histogram_device(fmt, d[split:], len(blocks) - split // fmt.block_bytes, hist=acc, accumulate=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy().astype(np.uint32), want + np.arange(16, dtype=np.uint32)), fmt.name
