@@ -377,6 +377,7 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	cw_hi += cw_hi & (ones << ((route >> 15) & 31u));
 	const uint32_t ibc = L.ibc, imask_c = L.imask_c, wmul_c = L.wmul_c, wadd_c = L.wadd_c;
 
+	constexpr int kGroup = FIXED >= 0 ? 4 : 1;
 	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
 	if (any_two) {
 		// alpha stream (modes 4/5: one subset, the only anchor is texel 0)
@@ -385,24 +386,40 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, L.half_a);
 		aw += aw & L.himask0_a;
 		const uint32_t iba = L.iba, imask_a = L.imask_a, wmul_a = L.wmul_a, wadd_a = L.wadd_a, sel_ba = L.sel_ba;
+		// texels in groups: the group's subset rows are requested together, so the wave waits for LDS once per group.  Same
+		// run, three passes each, U / M / C: groups of 1: 54.5 / 56.5 / 48.0 us, of 2: 54.7 / 56.2 / 48.0, of 4: 56.7 / 57.4 /
+		// 47.4 -- the mixed-mode path is better off waiting per texel (its registers are scarce), the uniform-wave copies
+		// (stream C) gain a little from four in flight
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			if (i == 8) { cw = cw_hi; aw = aw_hi; }
-			const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;	// weight = byte 2
-			cw >>= ibc;
-			const uint32_t ta = DETEX_UMUL24(aw & imask_a, wmul_a) + wadd_a;
-			aw >>= iba;
-			const uint4 s = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12));
-			d[i] = perm(pk_mad_u16(s.w, perm(ta, tc, sel_ba), s.y), pk_mad_u16_bhi(s.z, tc, s.x), gather);
+		for (int i0 = 0; i0 < 16; i0 += kGroup) {
+			uint4 s[kGroup];
+#pragma unroll
+			for (int j = 0; j < kGroup; j++) { const int i = i0 + j; s[j] = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12)); }
+#pragma unroll
+			for (int j = 0; j < kGroup; j++) {
+				const int i = i0 + j;
+				if (i == 8) { cw = cw_hi; aw = aw_hi; }
+				const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;	// weight = byte 2
+				cw >>= ibc;
+				const uint32_t ta = DETEX_UMUL24(aw & imask_a, wmul_a) + wadd_a;
+				aw >>= iba;
+				d[i] = perm(pk_mad_u16(s[j].w, perm(ta, tc, sel_ba), s[j].y), pk_mad_u16_bhi(s[j].z, tc, s[j].x), gather);
+			}
 		}
 	} else {
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			if (i == 8) cw = cw_hi;
-			const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;
-			cw >>= ibc;
-			const uint4 s = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12));
-			d[i] = perm(pk_mad_u16_bhi(s.w, tc, s.y), pk_mad_u16_bhi(s.z, tc, s.x), gather);
+		for (int i0 = 0; i0 < 16; i0 += kGroup) {
+			uint4 s[kGroup];
+#pragma unroll
+			for (int j = 0; j < kGroup; j++) { const int i = i0 + j; s[j] = lane.get_subset(i < 6 ? p_lo >> (2 * i) : pword >> (2 * i - 12)); }
+#pragma unroll
+			for (int j = 0; j < kGroup; j++) {
+				const int i = i0 + j;
+				if (i == 8) cw = cw_hi;
+				const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;
+				cw >>= ibc;
+				d[i] = perm(pk_mad_u16_bhi(s[j].w, tc, s[j].y), pk_mad_u16_bhi(s[j].z, tc, s[j].x), gather);
+			}
 		}
 	}
 	return true;
