@@ -141,7 +141,12 @@ template <uint32_t ALPHA> DH uint32_t etc_planar_texel(const EtcPlanar &c, uint3
 // Waves with more planar blocks (43 % of the blocks of the reference's ETC2 fixtures are planar) decode them in their own
 // lanes, on the path they always took.  Same run, 8192^2, stream U: ETC2_EAC 52.9 -> 50.4 us, ETC2 44.7 -> 43.1.  Purely wave-local: LDS operations of one wave
 // complete in order, no workgroup barrier; works for any set of active lanes (tasks are dealt to the active ones).
-constexpr int kEtcPlanarShared = 8;	// most planar blocks per wave that are decoded cooperatively (two passes of 64 texels)
+#if defined(DETEXHIP_EXP_PLANAR_SHARED)
+constexpr int kEtcPlanarShared = DETEXHIP_EXP_PLANAR_SHARED;
+#else
+constexpr int kEtcPlanarShared = 8;
+#endif
+	// most planar blocks per wave that are decoded cooperatively (two passes of 64 texels)
 struct alignas(16) EtcPlanarSlab { uint32_t coef[kEtcPlanarShared][8]; uint32_t texel[kEtcPlanarShared * 16]; };	// texel[16 * b + 4 * y + x]
 DH EtcPlanarSlab &etc_planar_slab() { __shared__ EtcPlanarSlab slabs[4]; return slabs[threadIdx.x >> 6]; }
 DH void wave_lds_sync() {
