@@ -13,6 +13,7 @@ for v in "$@"; do
     plain_persistent) D="-DDETEXHIP_EXP_BC7_PLAIN -DDETEXHIP_EXP_BC7_PERSISTENT" ;;
     sgprconst) D=-DDETEXHIP_EXP_SGPR_CONST ;;                 # v_bitop3 masks left in SGPRs (BC7 / BC6H)
     rgtc1g*) D=-DDETEXHIP_EXP_RGTC1_GROUP=${v#rgtc1g} ;;      # RGTC1 blocks per lane (1 = the one-block kernel)
+    planar[0-9]*) D=-DDETEXHIP_EXP_PLANAR_SHARED=${v#planar} ;; # most planar blocks per wave decoded cooperatively (default 8)
     planarinlane) D=-DDETEXHIP_EXP_PLANAR_IN_LANE ;;          # ETC2 planar blocks always decoded in their own lanes
     bc7stage) D=-DDETEXHIP_EXP_BC7_SEPARATE_STAGE ;;          # block-major BC7 with the separate 17 KiB staging array
     *) D="$EXP_DEFS" ;;
