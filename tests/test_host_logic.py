@@ -187,13 +187,15 @@ def _gloo_worker(rank, world, port, q):
         q.put((rank, "ERROR %r" % (e,)))
 
 
-def test_sharded_decode_and_gather_over_gloo_world2():
-    """the N>1 path (row-band shards + optional whole-image gather) with two CPU processes"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_decode_and_gather_over_gloo(world):
+    """the N>1 path (row-band shards + optional whole-image gather) with two / four CPU processes; with four ranks the 9-,
+    13- and 50-block-row images give bands of unequal height (the padded-chunk branch of gather_image)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
     got = [q.get(timeout=180) for _ in procs]
     for p in procs: p.join(timeout=60)
