@@ -313,6 +313,7 @@ DH Bc6hSignedUnq bc6h_signed_unq(uint32_t epb) {
 	const bool pass = epb >= 16u;
 	return Bc6hSignedUnq{ pass ? 0 : 1, pass ? 0 : -1, pass ? 1u : 17u - epb, pass ? 40000u : lim - 1u, pass ? 0x7FFFFFFFu : 2u * lim - 1u };
 }
+// (inline asm: left to itself the compiler builds the clamp from two compares and two selects)
 #if defined(__HIPCC__)
 DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { int32_t r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
 #else

@@ -68,12 +68,6 @@ DETEX_HD uint32_t rgtc_signed_to_16(int32_t v) {
 // ---- single-instruction bit-field idioms ---------------------------------------------------
 DH uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 DH int32_t sbfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_sbfe((int32_t)v, off, width); }
-// sign(x) in {-1, 0, 1} as one v_med3_i32 (left to itself the compiler builds it from two compares and two selects)
-#if defined(__HIPCC__)
-DH int32_t sign_of(int32_t x) { int32_t r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x)); return r; }
-#else
-DH int32_t sign_of(int32_t x) { return (x > 0) - (x < 0); }
-#endif
 // Lane masks are made OPAQUE to the optimiser.  Left visible, hipcc proves a mask is 0 / ~0 and
 // rewrites every (a & m) | (b & ~m) into v_cmp + v_cndmask_b32; runs of VOP2-encoded
 // v_cndmask_b32 issue at ~23 cycles each on MI355X (tools/ubench/valu_rates.hip: 23.3 vs 4.5 for
