@@ -5,9 +5,20 @@
 //   3  BPTC_FLOAT field scatter as a per-mode switch; BPTC round-1 decoder with register-select texel stage
 //   4  BPTC round-1 default decoder (LDS block fields, per-texel index widths) -- the baseline decode_bptc.h replaced
 //   5  BPTC with mode-sorted waves (workgroup counting sort by mode)
+//   6  persistent grid, twice as many workgroups as are resident at once (kernels_persistent.h)      [32-bit pixels]
+//   7  persistent grid, exactly the resident count
 // Included by detexhip.hip inside its anonymous namespace, after Geometry / PlainDecoder (the kernel headers
 // variant_tile4x4.h, decode_bptc_r01.h and kernels_sorted.h are included at file scope before it).
 #pragma once
+
+// workgroups of `kernel` that are resident at once on the current device
+template <class K> uint32_t resident_workgroups(K kernel) {
+	int per_cu = 0, cus = 0, dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0 || cus <= 0)
+		return 2048;
+	return (uint32_t)per_cu * (uint32_t)cus;
+}
 
 template <class Dec> struct AltDecoder { using type = Dec; };
 template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };
@@ -48,6 +59,15 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 	if constexpr (ClassSorted<Dec>::kAvailable && EpilogueOf<Dec, EPI>::kRowDwords == 4) {
 		if (g.variant == 5) {
 			hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
+	if constexpr (EpilogueOf<Dec, EPI>::kRowDwords != 8) {
+		if (g.variant == 6 || g.variant == 7) {
+			auto kernel = decode_linear_persistent<Dec, EPI>;
+			const uint32_t tiles = (n + 255u) / 256u, want = (g.variant == 6 ? 2u : 1u) * resident_workgroups(kernel);
+			hipLaunchKernelGGL(kernel, dim3(tiles < want ? tiles : want), block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 			*result = hipGetLastError();
 			return true;
 		}

@@ -85,78 +85,84 @@ constexpr Bc7PartTable bc7_part_table() {
 __constant__ Bc7PartTable kBc7PartTable = bc7_part_table();
 
 // ---- per-mode record ------------------------------------------------------------------------------------
+// 52 words in thirteen 16-byte groups, ordered by use: the decoder fetches a group with ONE ds_read_b128 (4 LDS cycles
+// for the wave) at the point where its fields are needed.  Left to field-wise reads the compiler issued ds_read_b96 (8
+// cycles) and ds_read2_b32 (4 cycles per 8 bytes) for the same bytes: about 40 of the 250 LDS cycles a wave spends per tile.
 constexpr uint32_t kBc7RowBytes = 1024u;	// LDS stride between a lane's consecutive block dwords ([row][lane], 256 lanes)
-struct alignas(16) Bc7Rec {
-	uint32_t pos_part, pb, pos_rot, rb;			// header fields of the first dword
-	uint32_t part_base, cb, ab, ns;				// part_base: BYTE offset of the mode's section of the partition table
-	uint32_t row_r, row_g, row_b, row_a;			// LDS row byte offset of the dword a channel's fields start in
-	uint32_t pos_r, pos_g, pos_b, pos_a;			// their bit positions (v_alignbit_b32 uses the low 5 bits)
-	uint32_t row_p, pos_p, p_word_mask, up_c;		// P-bits; QUIRK A-2 mask; colour shift-up 8 - cb
-	uint32_t down_c, up_ba, down_ba, pconst_rg;		// packed per-16-bit-lane shift amounts; P-bit place in (R,G)
-	uint32_t pconst_ba, set_ba, pidx0, pidx1;		// P-bit place in (B,A); alpha = 255 for modes 0-3; P-bit of endpoint e
-	uint32_t pidx2, pidx3, pidx4, pidx5;
-	uint32_t row_c, pos_c, ibc, imask_c;			// colour index stream
-	uint32_t wmul_c, wadd_c, himask0_c, two;		// weight = byte 2 of index * mul + add; texel 0's anchor bit; has a second stream
-	uint32_t row_a2, pos_a2, iba, imask_a;			// alpha index stream (modes 4, 5)
-	uint32_t wmul_a, wadd_a, himask0_a, half_a;
-	uint32_t sel_ba, mode, ins_ones, pad1;			// v_perm selector building (colour weight, alpha weight); ~0 if the mode has partitions
+enum Bc7Field : int {
+	F_POS_PART, F_PB, F_POS_ROT, F_RB,			// G0  header fields of the first dword
+	F_PART_BASE, F_NS, F_MODE, F_TWO,			// G1  BYTE offset of the mode's section of the partition table; subsets; mode; has a second index stream
+	F_ROW_R, F_ROW_G, F_ROW_B, F_ROW_A,			// G2  LDS row byte offset of the dword a channel's fields start in
+	F_POS_R, F_POS_G, F_POS_B, F_POS_A,			// G3  their bit positions (v_alignbit_b32 uses the low 5 bits)
+	F_ROW_P, F_POS_P, F_P_WORD_MASK, F_CB,			// G4  P-bits; QUIRK A-2 mask; colour bits
+	F_AB, F_UP_C, F_DOWN_C, F_PCONST_RG,			// G5  alpha bits; colour shift-up 8 - cb; packed per-16-bit-lane shift amounts; P-bit place in (R,G)
+	F_UP_BA, F_DOWN_BA, F_PCONST_BA, F_SET_BA,		// G6  the same for (B,A); alpha = 255 for modes 0-3
+	F_PIDX0, F_PIDX1, F_PIDX2, F_PIDX3,			// G7  P-bit of endpoint e
+	F_PIDX4, F_PIDX5, F_INS_ONES, F_HIMASK0_C,		// G8  ~0 if the mode has partitions; texel 0's anchor bit (colour stream)
+	F_ROW_C, F_POS_C, F_IBC, F_IMASK_C,			// G9  colour index stream
+	F_WMUL_C, F_WADD_C, F_SEL_BA, F_HALF_A,			// G10 weight = byte 2 of index * mul + add; v_perm selector (colour weight, alpha weight)
+	F_ROW_A2, F_POS_A2, F_IBA, F_IMASK_A,			// G11 alpha index stream (modes 4, 5)
+	F_WMUL_A, F_WADD_A, F_HIMASK0_A, F_PAD,			// G12
+	kBc7RecWords
 };
+struct alignas(16) Bc7Rec { uint32_t w[kBc7RecWords]; };
 static_assert(sizeof(Bc7Rec) == 208, "record is fetched with 16-byte LDS reads; 52-dword stride keeps records on disjoint banks");
 constexpr int kBc7Recs = 9;
 
 constexpr Bc7Rec bc7_rec(uint32_t mode, bool isel) {
 	const Bc7ModeDesc m = kBc7Modes[mode];
 	Bc7Rec L = {};
-	L.mode = mode;
-	L.pos_part = mode + 1u; L.pb = m.pb;
-	L.pos_rot = L.pos_part + m.pb; L.rb = m.rb;
-	const uint32_t pos_isel = L.pos_rot + m.rb;
+	L.w[F_MODE] = mode;
+	L.w[F_POS_PART] = mode + 1u; L.w[F_PB] = m.pb;
+	L.w[F_POS_ROT] = mode + 1u + m.pb; L.w[F_RB] = m.rb;
+	const uint32_t pos_isel = mode + 1u + m.pb + m.rb;
 	const uint32_t chan = 2u * m.ns * m.cb;
 	const uint32_t pos_r = pos_isel + m.isb, pos_g = pos_r + chan, pos_b = pos_g + chan, pos_a = pos_b + chan;
 	const uint32_t pos_p = pos_a + 2u * m.ns * m.ab;
 	const uint32_t pos_idx = pos_p + m.epb * 2u * m.ns + m.spb * m.ns;
 	const uint32_t pos_idx2 = pos_idx + 16u * m.ib - m.ns;
-	L.cb = m.cb; L.ab = m.ab; L.ns = m.ns;
-	L.part_base = (uint32_t)sizeof(Bc7PartEntry) *
+	L.w[F_CB] = m.cb; L.w[F_AB] = m.ab; L.w[F_NS] = m.ns;
+	L.w[F_PART_BASE] = (uint32_t)sizeof(Bc7PartEntry) *
 		(m.ns == 1u ? 208u + ((isel ? m.ib2 : m.ib) - 2u) : (m.ns == 2u ? (m.ib == 2u ? 0u : 64u) : (m.ib == 2u ? 128u : 192u)));
-	L.row_r = (pos_r >> 5) * kBc7RowBytes; L.row_g = (pos_g >> 5) * kBc7RowBytes;
-	L.row_b = (pos_b >> 5) * kBc7RowBytes; L.row_a = (pos_a >> 5) * kBc7RowBytes;
-	L.pos_r = pos_r; L.pos_g = pos_g; L.pos_b = pos_b; L.pos_a = pos_a;
-	L.row_p = (pos_p >> 5) * kBc7RowBytes; L.pos_p = pos_p;
-	L.p_word_mask = mode == 6u ? 1u : 0xFFFFFFFFu;			// QUIRK A-2 (decompress-bptc.c:142-146)
+	L.w[F_ROW_R] = (pos_r >> 5) * kBc7RowBytes; L.w[F_ROW_G] = (pos_g >> 5) * kBc7RowBytes;
+	L.w[F_ROW_B] = (pos_b >> 5) * kBc7RowBytes; L.w[F_ROW_A] = (pos_a >> 5) * kBc7RowBytes;
+	L.w[F_POS_R] = pos_r; L.w[F_POS_G] = pos_g; L.w[F_POS_B] = pos_b; L.w[F_POS_A] = pos_a;
+	L.w[F_ROW_P] = (pos_p >> 5) * kBc7RowBytes; L.w[F_POS_P] = pos_p;
+	L.w[F_P_WORD_MASK] = mode == 6u ? 1u : 0xFFFFFFFFu;			// QUIRK A-2 (decompress-bptc.c:142-146)
 	// 8-bit expansion of a cb-bit value v with optional P-bit p (decompress-bptc.c:136-180):
 	//   (v << (8 - cb)) | (p << (7 - cb)) | (v >> (cb + cprec - 8)),  cprec = cb + has_p
 	const uint32_t has_p = m.epb | m.spb, cprec = m.cb + has_p, aprec = m.ab + m.epb;
 	const uint32_t up_c = 8u - m.cb, down_c = m.cb + cprec - 8u;
 	const uint32_t up_a = m.ab ? 8u - m.ab : 0u, down_a = m.ab ? m.ab + aprec - 8u : 0u;
-	L.up_c = up_c;
-	L.down_c = down_c * 0x00010001u;
-	L.up_ba = up_c | (up_a << 16);
-	L.down_ba = down_c | (down_a << 16);
+	L.w[F_UP_C] = up_c;
+	L.w[F_DOWN_C] = down_c * 0x00010001u;
+	L.w[F_UP_BA] = up_c | (up_a << 16);
+	L.w[F_DOWN_BA] = down_c | (down_a << 16);
 	const uint32_t pc = has_p ? 1u << (7u - m.cb) : 0u, pa = (m.ab && m.epb) ? 1u << (7u - m.ab) : 0u;
-	L.pconst_rg = pc * 0x00010001u;
-	L.pconst_ba = pc | (pa << 16);
-	L.set_ba = m.ab ? 0u : 0x00FF0000u;				// modes 0-3 are opaque (:176-179)
+	L.w[F_PCONST_RG] = pc * 0x00010001u;
+	L.w[F_PCONST_BA] = pc | (pa << 16);
+	L.w[F_SET_BA] = m.ab ? 0u : 0x00FF0000u;				// modes 0-3 are opaque (:176-179)
 	// P-bit of endpoint e: its own (epb), its subset's (spb, mode 1), none (pconst = 0)
 	const uint32_t sh = m.spb ? 1u : 0u;
-	L.pidx0 = 0u >> sh; L.pidx1 = 1u >> sh; L.pidx2 = 2u >> sh; L.pidx3 = 3u >> sh; L.pidx4 = 4u >> sh; L.pidx5 = 5u >> sh;
+	for (uint32_t e = 0; e < 4u; e++) L.w[F_PIDX0 + e] = e >> sh;
+	L.w[F_PIDX4] = 4u >> sh; L.w[F_PIDX5] = 5u >> sh;
 	// index streams (:401-480): primary 16*ib - ns bits, then (modes 4/5) the secondary one; the colour stream is
 	// the primary one unless the index-selection bit swaps them (:374-375, 452-480)
 	const bool two = m.ib2 != 0u;
 	const uint32_t ibc = (two && isel) ? m.ib2 : m.ib, iba = two ? (isel ? m.ib : m.ib2) : m.ib;
 	const uint32_t pos_c = (two && isel) ? pos_idx2 : pos_idx, pos_a2 = two ? (isel ? pos_idx : pos_idx2) : 0u;
-	L.row_c = (pos_c >> 5) * kBc7RowBytes; L.pos_c = pos_c; L.ibc = ibc; L.imask_c = (1u << ibc) - 1u;
-	L.wmul_c = bptc_weight_mul(ibc); L.wadd_c = bptc_weight_add(ibc);
-	L.himask0_c = 0xFFFFFFFFu << (ibc - 1u);
-	L.two = two ? 1u : 0u;
-	L.row_a2 = (pos_a2 >> 5) * kBc7RowBytes; L.pos_a2 = pos_a2; L.iba = iba; L.imask_a = (1u << iba) - 1u;
-	L.wmul_a = bptc_weight_mul(iba); L.wadd_a = bptc_weight_add(iba);
-	L.himask0_a = 0xFFFFFFFFu << (iba - 1u);
-	L.half_a = 8u * iba - 1u;
+	L.w[F_ROW_C] = (pos_c >> 5) * kBc7RowBytes; L.w[F_POS_C] = pos_c; L.w[F_IBC] = ibc; L.w[F_IMASK_C] = (1u << ibc) - 1u;
+	L.w[F_WMUL_C] = bptc_weight_mul(ibc); L.w[F_WADD_C] = bptc_weight_add(ibc);
+	L.w[F_HIMASK0_C] = 0xFFFFFFFFu << (ibc - 1u);
+	L.w[F_TWO] = two ? 1u : 0u;
+	L.w[F_ROW_A2] = (pos_a2 >> 5) * kBc7RowBytes; L.w[F_POS_A2] = pos_a2; L.w[F_IBA] = iba; L.w[F_IMASK_A] = (1u << iba) - 1u;
+	L.w[F_WMUL_A] = bptc_weight_mul(iba); L.w[F_WADD_A] = bptc_weight_add(iba);
+	L.w[F_HIMASK0_A] = 0xFFFFFFFFu << (iba - 1u);
+	L.w[F_HALF_A] = 8u * iba - 1u;
 	// (colour weight, alpha weight) in 16-bit lanes from byte 2 of the two mads; blocks without a second stream
 	// use the colour weight twice
-	L.sel_ba = two ? 0x0C060C02u : 0x0C020C02u;
-	L.ins_ones = m.ns == 1u ? 0u : 0xFFFFFFFFu;
+	L.w[F_SEL_BA] = two ? 0x0C060C02u : 0x0C020C02u;
+	L.w[F_INS_ONES] = m.ns == 1u ? 0u : 0xFFFFFFFFu;
 	return L;
 }
 struct Bc7RecTable { Bc7Rec r[kBc7Recs]; };
@@ -205,13 +211,8 @@ struct Bc7Lds {
 	// i.e. up to 2 KiB past this array -- LDS reads beyond the allocation return 0 rather than faulting, and whatever
 	// they return stands for bits beyond 127, which no field or index ever consumes
 	alignas(16) uint32_t bits[4][256];	// (16-byte aligned: the block-major exchange stages 16-byte vectors here, stage_slot)
-#if defined(DETEXHIP_EXP_LDS_PAD)		// measurement build: lower the occupancy
-	uint32_t pad[DETEXHIP_EXP_LDS_PAD / 4];
-#endif
 };
-#if !defined(DETEXHIP_EXP_LDS_PAD)
-static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU");
-#endif
+static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU by LDS (the round-2 occupancy sweep padded this struct: DESIGN.md section 5)");
 DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
 // (Requesting the kernel's first block between the table load and its LDS store -- so that the block travels during the
 // barrier -- was measured too: the compiler issues the block load first either way, and then the barrier waits for the
@@ -234,10 +235,10 @@ struct Bc7Lane {
 		bits_base = (uint32_t)(uintptr_t)&s.bits[0][threadIdx.x];
 		subset_base = (uint32_t)(uintptr_t)&s.subset[0][threadIdx.x];
 		subset_bits = 0x3000u;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
+#if defined(__HIP_DEVICE_COMPILE__)
 		// v_bitop3_b32 is VOP3 and takes no literal on gfx950: the compiler would keep the mask in an SGPR, and a full-rate
 		// VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr / bitop3_sgpr)
-		asm volatile("" : "+v"(subset_bits));
+		if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(subset_bits));
 #endif
 	}
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -265,10 +266,19 @@ struct Bc7Lane {
 		const u32x4 v = *(const lds_u4 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(sel, subset_bits, subset_base, 0xEA);
 		return uint4{ v.x, v.y, v.z, v.w };
 	}
-	static DH const Bc7Rec &rec(uint32_t r) {
-		uint32_t off = r * (uint32_t)sizeof(Bc7Rec);
-		asm("" : "+v"(off));	// one opaque byte offset: the fields then come as immediate offsets of a few wide LDS reads
-		return *reinterpret_cast<const Bc7Rec *>(reinterpret_cast<const char *>(bc7_lds().t.rec) + off);
+	// byte address of record r in the workgroup's LDS image, opaque to the optimiser: the groups then come as
+	// immediate offsets from one address register
+	static DH uint32_t rec_address(uint32_t r) {
+		uint32_t a = (uint32_t)(uintptr_t)bc7_lds().t.rec + r * (uint32_t)sizeof(Bc7Rec);
+		asm("" : "+v"(a));
+		return a;
+	}
+	// group G (four consecutive words) of the record at `address`: ONE ds_read_b128, kept whole by pinning all four
+	// dwords at the point of the read (the compiler otherwise narrows it to ds_read_b96 / ds_read2_b32 when a word is unused)
+	template <int G> static DH uint4 rec_group(uint32_t address) {
+		u32x4 v = *(const lds_u4 *)(uintptr_t)(address + 16u * G);
+		asm volatile("" : "+v"(v));
+		return uint4{ v.x, v.y, v.z, v.w };
 	}
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) {
 		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().t.part) + byte_offset);
@@ -290,18 +300,37 @@ struct Bc7Lane {
 	}
 	DH void put_subset(int s, uint4 v) { subset[s] = v; }
 	DH uint4 get_subset(uint32_t sel) const { return subset[(sel >> 12) & 3u]; }
-	static DH const Bc7Rec &rec(uint32_t r) { return kBc7RecTable.r[r]; }
+	static DH uint32_t rec_address(uint32_t r) { return r; }
+	template <int G> static DH uint4 rec_group(uint32_t r) {
+		const uint32_t *w = kBc7RecTable.r[r].w + 4 * G;
+		return uint4{ w[0], w[1], w[2], w[3] };
+	}
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) { return kBc7PartTable.e[byte_offset / sizeof(Bc7PartEntry)]; }
 	static DH uint32_t gather(uint32_t rot) { return kBc7Gather[rot]; }
 #endif
 };
 
 // FIXED >= 0: the record is a compile-time constant (every lane of the wave is known to use record FIXED)
+template <int FIXED> struct Bc7RecReader {
+	uint32_t address;
+	DH explicit Bc7RecReader(uint32_t rec_index) : address(FIXED >= 0 ? 0u : Bc7Lane::rec_address(rec_index)) {}
+	template <int G> DH uint4 group() const {
+		if constexpr (FIXED >= 0) {
+			constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
+			return uint4{ kFixed.w[4 * G], kFixed.w[4 * G + 1], kFixed.w[4 * G + 2], kFixed.w[4 * G + 3] };
+		} else {
+			return Bc7Lane::rec_group<G>(address);
+		}
+	}
+};
+
 template <int FIXED, bool CHECKED>
 DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 	constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
-	const Bc7Rec &L = FIXED >= 0 ? kFixed : Bc7Lane::rec(rec_index);
-	const uint32_t mode = L.mode;
+	const Bc7RecReader<FIXED> L(rec_index);
+	const uint4 g_head = L.template group<F_POS_PART / 4>();	// pos_part, pb, pos_rot, rb
+	const uint4 g_part = L.template group<F_PART_BASE / 4>();	// part_base, ns, mode, two
+	const uint32_t mode = g_part.z;
 	if (CHECKED) {							// decompress-bptc.c:363-369
 		if (!(mode_mask & (1u << mode))) return false;
 		if (mode >= 4u && (flags & kFlagOpaqueOnly)) return false;
@@ -309,27 +338,34 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	}
 	Bc7Lane lane;
 	lane.put_bits(blk);
+	stage_priority<Tune::kBc7Prio, 0>();
 
 	// header fields all lie in the first 14 bits
-	const uint32_t part = ubfe(blk.x, L.pos_part, L.pb);
-	const uint32_t rot = ubfe(blk.x, L.pos_rot, L.rb);
-	const Bc7PartEntry &pe = Bc7Lane::part(DETEX_UMUL24(part, (uint32_t)sizeof(Bc7PartEntry)) + L.part_base);
+	const uint32_t part = ubfe(blk.x, g_head.x, g_head.y);
+	const uint32_t rot = ubfe(blk.x, g_head.z, g_head.w);
+	const Bc7PartEntry &pe = Bc7Lane::part(DETEX_UMUL24(part, (uint32_t)sizeof(Bc7PartEntry)) + g_part.x);
 	const uint32_t gather = Bc7Lane::gather(rot);
 
 	// wave-uniform trimming: endpoints of subsets no lane of the wave has are not expanded, alpha fields are
 	// skipped in waves of opaque modes, the second index stream in waves without modes 4/5 (the uniform-random
 	// stream has all of them in nearly every wave; encoder output mostly does not)
-	const uint32_t wave_subsets = FIXED >= 0 ? kFixed.ns
-		: (__builtin_amdgcn_ballot_w64(L.ns == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(L.ns == 2u) ? 2u : 1u));
-	const bool wave_alpha = FIXED >= 0 ? kFixed.ab != 0u : __builtin_amdgcn_ballot_w64(mode >= 4u) != 0;
-	const bool any_two = FIXED >= 0 ? kFixed.two != 0u : __builtin_amdgcn_ballot_w64(L.two != 0u) != 0;
+	const uint32_t wave_subsets = FIXED >= 0 ? kFixed.w[F_NS]
+		: (__builtin_amdgcn_ballot_w64(g_part.y == 3u) ? 3u : (__builtin_amdgcn_ballot_w64(g_part.y == 2u) ? 2u : 1u));
+	const bool wave_alpha = FIXED >= 0 ? kFixed.w[F_AB] != 0u : __builtin_amdgcn_ballot_w64(mode >= 4u) != 0;
+	const bool any_two = FIXED >= 0 ? kFixed.w[F_TWO] != 0u : __builtin_amdgcn_ballot_w64(g_part.w != 0u) != 0;
 
 	// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values), then the P-bits (:74-132)
-	const uint32_t wr = lane.field(L.row_r, L.pos_r), wg = lane.field(L.row_g, L.pos_g), wb = lane.field(L.row_b, L.pos_b);
-	const uint32_t wa = wave_alpha ? lane.field(L.row_a, L.pos_a) : 0u;
-	const uint32_t pw = lane.field(L.row_p, L.pos_p) & L.p_word_mask;
-	const uint32_t cb = L.cb, ab = L.ab;
-	const uint32_t pidx[6] = { L.pidx0, L.pidx1, L.pidx2, L.pidx3, L.pidx4, L.pidx5 };
+	const uint4 g_row = L.template group<F_ROW_R / 4>(), g_pos = L.template group<F_POS_R / 4>();
+	const uint32_t wr = lane.field(g_row.x, g_pos.x), wg = lane.field(g_row.y, g_pos.y), wb = lane.field(g_row.z, g_pos.z);
+	const uint32_t wa = wave_alpha ? lane.field(g_row.w, g_pos.w) : 0u;
+	const uint4 g_p = L.template group<F_ROW_P / 4>();		// row_p, pos_p, p_word_mask, cb
+	const uint32_t pw = lane.field(g_p.x, g_p.y) & g_p.z;
+	const uint4 g_c = L.template group<F_AB / 4>();			// ab, up_c, down_c, pconst_rg
+	const uint4 g_ba = L.template group<F_UP_BA / 4>();		// up_ba, down_ba, pconst_ba, set_ba
+	const uint4 g_pi = L.template group<F_PIDX0 / 4>();		// pidx0..3
+	const uint4 g_pj = L.template group<F_PIDX4 / 4>();		// pidx4, pidx5, ins_ones, himask0_c
+	const uint32_t cb = g_p.w, ab = g_c.x;
+	const uint32_t pidx[6] = { g_pi.x, g_pi.y, g_pi.z, g_pi.w, g_pj.x, g_pj.y };
 	uint32_t x_rg[6], x_ba[6];
 	uint32_t off = 0u, offa = 0u;
 #pragma unroll
@@ -340,8 +376,8 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 		uint32_t ba = ubfe(wb, off, cb);
 		if (e < 4) ba |= ubfe(wa, offa, ab) << 16;		// modes with alpha have at most two subsets; ab = 0 reads 0
 		const uint32_t pm = (uint32_t)sbfe(pw, pidx[e], 1u);			// 0 / ~0: this endpoint's P-bit
-		x_rg[e] = or3(rg << L.up_c, pk_lshr_v(L.down_c, rg), pm & L.pconst_rg);
-		x_ba[e] = or3(pk_lshl_v(L.up_ba, ba), pk_lshr_v(L.down_ba, ba), and_or(pm, L.pconst_ba, L.set_ba));
+		x_rg[e] = or3(rg << g_c.y, pk_lshr_v(g_c.z, rg), pm & g_c.w);
+		x_ba[e] = or3(pk_lshl_v(g_ba.x, ba), pk_lshr_v(g_ba.y, ba), and_or(pm, g_ba.z, g_ba.w));
 		off = FIXED >= 0 ? off + cb : opaque(off + cb);		// running sums as plain adds (opaque: not re-derived as e * cb with shifts)
 		offa = FIXED >= 0 ? offa + ab : opaque(offa + ab);
 	}
@@ -359,33 +395,38 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 		lane.put_subset(s, row);
 	}
 
+	stage_priority<Tune::kBc7Prio, 1>();
 	// subset number of texel i at bits 12-13 of (p_lo >> 2i) for i < 6, of (pword >> (2i - 12)) above: right shifts only
 	const uint32_t pword = pe.pword, p_lo = pword << 12;
 
 	// Colour index stream: 64 stream bits from its start; texels 0-7 consume `half` of them, texels 8-15 start
 	// there.  Each window then gets the anchors' absent top bits inserted as zeros (w + (w & himask) doubles the
 	// part of w at and above the insertion point), after which texel k of a window sits at bit k*ib.
+	const uint4 g_ci = L.template group<F_ROW_C / 4>();		// row_c, pos_c, ibc, imask_c
+	const uint4 g_cw = L.template group<F_WMUL_C / 4>();		// wmul_c, wadd_c, sel_ba, half_a
 	uint32_t c0, c1;
-	lane.field64(L.row_c, L.pos_c, c0, c1);
+	lane.field64(g_ci.x, g_ci.y, c0, c1);
 	const uint32_t route = pe.route;			// shifts use the low 5 bits of their amount
 	uint32_t cw = c0, cw_hi = __builtin_amdgcn_alignbit(c1, c0, route >> 20);
-	cw += cw & L.himask0_c;
-	const uint32_t ones = L.ins_ones;
+	cw += cw & g_pj.w;
+	const uint32_t ones = g_pj.z;
 	cw += cw & (ones << (route & 31u));
 	cw += cw & (ones << ((route >> 5) & 31u));
 	cw_hi += cw_hi & (ones << ((route >> 10) & 31u));
 	cw_hi += cw_hi & (ones << ((route >> 15) & 31u));
-	const uint32_t ibc = L.ibc, imask_c = L.imask_c, wmul_c = L.wmul_c, wadd_c = L.wadd_c;
+	const uint32_t ibc = g_ci.z, imask_c = g_ci.w, wmul_c = g_cw.x, wadd_c = g_cw.y;
 
-	constexpr int kGroup = FIXED >= 0 ? 4 : 1;
+	constexpr int kGroup = FIXED >= 0 ? Tune::kBc7UniformTexelGroup : 1;
 	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
 	if (any_two) {
 		// alpha stream (modes 4/5: one subset, the only anchor is texel 0)
+		const uint4 g_ai = L.template group<F_ROW_A2 / 4>();	// row_a2, pos_a2, iba, imask_a
+		const uint4 g_aw = L.template group<F_WMUL_A / 4>();	// wmul_a, wadd_a, himask0_a, -
 		uint32_t a0, a1;
-		lane.field64(L.row_a2, L.pos_a2, a0, a1);
-		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, L.half_a);
-		aw += aw & L.himask0_a;
-		const uint32_t iba = L.iba, imask_a = L.imask_a, wmul_a = L.wmul_a, wadd_a = L.wadd_a, sel_ba = L.sel_ba;
+		lane.field64(g_ai.x, g_ai.y, a0, a1);
+		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, g_cw.w);
+		aw += aw & g_aw.z;
+		const uint32_t iba = g_ai.z, imask_a = g_ai.w, wmul_a = g_aw.x, wadd_a = g_aw.y, sel_ba = g_cw.z;
 		// texels in groups: the group's subset rows are requested together, so the wave waits for LDS once per group.  Same
 		// run, three passes each, U / M / C: groups of 1: 54.5 / 56.5 / 48.0 us, of 2: 54.7 / 56.2 / 48.0, of 4: 56.7 / 57.4 /
 		// 47.4 -- the mixed-mode path is better off waiting per texel (its registers are scarce), the uniform-wave copies
@@ -398,7 +439,7 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 #pragma unroll
 			for (int j = 0; j < kGroup; j++) {
 				const int i = i0 + j;
-				if (i == 8) { cw = cw_hi; aw = aw_hi; }
+				if (i == 8) { cw = cw_hi; aw = aw_hi; stage_priority<Tune::kBc7Prio, 2>(); }
 				const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;	// weight = byte 2
 				cw >>= ibc;
 				const uint32_t ta = DETEX_UMUL24(aw & imask_a, wmul_a) + wadd_a;
@@ -415,7 +456,7 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 #pragma unroll
 			for (int j = 0; j < kGroup; j++) {
 				const int i = i0 + j;
-				if (i == 8) cw = cw_hi;
+				if (i == 8) { cw = cw_hi; stage_priority<Tune::kBc7Prio, 2>(); }
 				const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;
 				cw >>= ibc;
 				d[i] = perm(pk_mad_u16_bhi(s[j].w, tc, s[j].y), pk_mad_u16_bhi(s[j].z, tc, s[j].x), gather);
@@ -435,35 +476,23 @@ DH uint32_t bc7_record_index(uint32_t first_dword) {
 // throughput path -- clipped geometry, the checked per-block batch -- instantiate the plain form to bound code size)
 template <bool UNIFORM> struct DecBPTCT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4;
-#if defined(DETEXHIP_EXP_BC7_WAVES)
-	static constexpr int kWavesPerSimd = DETEXHIP_EXP_BC7_WAVES;
-#else
 	// <= 80 VGPRs: six waves per SIMD.  Same-run measurements on stream U / C: 64 VGPRs (9 dwords spilled) 65 / 52.4 us;
 	// 72 VGPRs 59.1 / 52.7 before the next tile's block was really prefetched, 59.1 / 52.2 with it (two dwords spilled,
 	// +2.5 % HBM traffic); 80 VGPRs (no spill) 57.9 / 50.8.  LDS (<= 20 KiB per workgroup) would admit eight workgroups.
-	static constexpr int kWavesPerSimd = 6;
-#endif
-	// One workgroup per tile, like every other decoder.  A persistent grid (workgroups looping over tiles, the 3.6 KiB of
-	// tables copied once per resident workgroup, the next tile's block prefetched) was the better choice while the tables
-	// were 7.5 KiB (58.8 vs 62.0 us, stream U); with today's tables it is the worse one -- same run, 8192^2, streams U / C:
-	// persistent 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (kernels.h keeps the persistent path for
-	// -DDETEXHIP_EXP_BC7_PERSISTENT).
-	// The block-major kernel likewise (same run, U / M / C: persistent 62.5-63.3 / 63.8-64.7 / 52.0, one tile per
-	// workgroup 64.5 / 66.1 / 47.4: real content is the C case).
-#if defined(DETEXHIP_EXP_BC7_PERSISTENT)	// measurement build
-	static constexpr bool kPersistent = true, kPersistentBlocks = true;
-#else
-	static constexpr bool kPersistent = false, kPersistentBlocks = false;
-#endif
+	static constexpr int kWavesPerSimd = Tune::kBc7WavesPerSimd;
+	// One workgroup per tile, like every other decoder.  A persistent grid (workgroups looping over tiles, the tables copied
+	// once per resident workgroup, the next tile's block prefetched) was the better choice while the tables were 7.5 KiB
+	// (58.8 vs 62.0 us, stream U); with today's 3.6 KiB it is the worse one -- same run, 8192^2, streams U / C: persistent
+	// 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (ab/kernels_persistent.h keeps that kernel for the
+	// measurement build).  The block-major kernel likewise (U / M / C: 62.5-63.3 / 63.8-64.7 / 52.0 vs 64.5 / 66.1 / 47.4).
 #if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
-#if !defined(DETEXHIP_EXP_BC7_SEPARATE_STAGE)
 	// 16-byte staging slot of the block-major exchange (kernels.h: decode_blocks) inside this wave's own lane rows, which
 	// are dead once a tile is decoded: vector k (0..3) of the wave's block b (0..63).  Vectors 0-2 live in the wave's
 	// 1 KiB of subset row k, rotated by 2k slots so that the transposed reads (four consecutive lanes = the four vectors
 	// of one block) fall on different banks; vector 3 in the wave's four 256-byte pieces of the block-dword rows.  A
 	// separate 17 KiB staging array left four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
-	static constexpr bool kOwnStage = true;
+	static constexpr bool kOwnStage = Tune::kBc7OwnStage;
 	static DH void *stage_slot(uint32_t k, uint32_t b) {
 		Bc7Lds &s = bc7_lds();
 		const uint32_t w = threadIdx.x >> 6, p = (b + 2u * k) & 63u;
@@ -471,7 +500,6 @@ template <bool UNIFORM> struct DecBPTCT {
 		char *in_bits = reinterpret_cast<char *>(&s.bits[0][64u * w]) + (p >> 4) * (uint32_t)sizeof(s.bits[0]) + (p & 15u) * 16u;
 		return k < 3u ? in_rows : in_bits;
 	}
-#endif
 #endif
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		if ((blk.x & 0xFFu) == 0u) return false;		// reserved (decompress-bptc.c:229-237, 361)
@@ -497,11 +525,7 @@ template <bool UNIFORM> struct DecBPTCT {
 		return bc7_decode_with<-1, CHECKED>(blk, r, mode_mask, flags, d);
 	}
 };
-#if defined(DETEXHIP_EXP_BC7_PLAIN)		// measurement build: no wave-uniform specialisations
-using DecBPTC = DecBPTCT<false>;
-#else
-using DecBPTC = DecBPTCT<true>;
-#endif
+using DecBPTC = DecBPTCT<Tune::kBc7Uniform>;
 using DecBPTCPlain = DecBPTCT<false>;
 
 }  // namespace detexhip

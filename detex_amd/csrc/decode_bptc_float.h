@@ -228,10 +228,10 @@ struct Bc6hLane {
 		base_a = (uint32_t)(uintptr_t)&s.row_a[0][threadIdx.x];
 		base_b = (uint32_t)(uintptr_t)&s.row_b[0][threadIdx.x];
 		bit12 = 0x1000u; bit11 = 0x800u;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
+#if defined(__HIP_DEVICE_COMPILE__)
 		// v_bitop3_b32 is VOP3 (no literal operand on gfx950): left alone the compiler keeps the masks in SGPRs, and a
 		// full-rate VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr, bitop3_sgpr)
-		asm volatile("" : "+v"(bit12), "+v"(bit11));
+		if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(bit12), "+v"(bit11));
 #endif
 	}
 	DH void put(int sub, uint4 a, uint2 b) const {
@@ -348,6 +348,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr bool kZeroOnFailure = true;
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t, uint32_t (&d)[32]) {
 		// :23-33: 2-bit codes 00/01 = modes 0/1, otherwise a 5-bit code; 10011,10111,11011,11111 reserved
+		stage_priority<Tune::kBc6hPrio, 0>();
 		const uint32_t low2 = blk.x & 3u, low5 = blk.x & 0x1Fu;
 		const uint32_t coded = low2 < 2u ? low2 : (low2 == 2u ? 2u + (low5 >> 2) : 10u + (low5 >> 2));
 		const bool valid = coded <= 13u && (!CHECKED || (mode_mask & (1u << (coded & 31u))) != 0u);
@@ -445,14 +446,15 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
 			lane.put(s, ra, rb);
 		}
+		stage_priority<Tune::kBc6hPrio, 1>();
 		const uint32_t p12 = pe.pmask12, p11 = p12 >> 1;
 		uint32_t b_even = 0, sign_bits = 0x80008000u;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_SGPR_CONST)
-		if (SIGNED) asm volatile("" : "+v"(sign_bits));
+#if defined(__HIP_DEVICE_COMPILE__)
+		if constexpr (SIGNED && Tune::kMasksInVgprs) asm volatile("" : "+v"(sign_bits));
 #endif
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
-			if (i == 8) win = win_hi;
+			if (i == 8) { win = win_hi; stage_priority<Tune::kBc6hPrio, 2>(); }
 			const int32_t w = (int32_t)((DETEX_UMUL24(win & imask, wmul) + wadd) >> 16);
 			win >>= ibits;
 			uint4 ra; uint2 rb;

@@ -133,7 +133,7 @@ template <uint32_t ALPHA> DH uint32_t etc_planar_texel(const EtcPlanar &c, uint3
 	return EtcGather<ALPHA>::template sat<0>(sat_u8_pk16(pk_ashr16(g, 2)), sat_u8_pk16(pk_ashr16(rb, 2)));
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_PLANAR_IN_LANE)
+#if defined(__HIP_DEVICE_COMPILE__)
 // Planar blocks are rare among other blocks (1 in 36 of a random stream, the smooth patches of real textures), yet a wave
 // with a single one executes the whole 16-texel planar path: ~125 VALU instructions on top of the ~300 of the palette modes.
 // When a wave holds at most eight of them, the owners only derive the six coefficients and park them in LDS; the wave's
@@ -141,13 +141,11 @@ template <uint32_t ALPHA> DH uint32_t etc_planar_texel(const EtcPlanar &c, uint3
 // Waves with more planar blocks (43 % of the blocks of the reference's ETC2 fixtures are planar) decode them in their own
 // lanes, on the path they always took.  Same run, 8192^2, stream U: ETC2_EAC 52.9 -> 50.4 us, ETC2 44.7 -> 43.1.  Purely wave-local: LDS operations of one wave
 // complete in order, no workgroup barrier; works for any set of active lanes (tasks are dealt to the active ones).
-#if defined(DETEXHIP_EXP_PLANAR_SHARED)
-constexpr int kEtcPlanarShared = DETEXHIP_EXP_PLANAR_SHARED;
-#else
-constexpr int kEtcPlanarShared = 8;
-#endif
-	// most planar blocks per wave that are decoded cooperatively (two passes of 64 texels)
-struct alignas(16) EtcPlanarSlab { uint32_t coef[kEtcPlanarShared][8]; uint32_t texel[kEtcPlanarShared * 16]; };	// texel[16 * b + 4 * y + x]
+// most planar blocks per wave that are decoded cooperatively (8 = two passes of 64 texels; thresholds 4 / 8 / 16 measured equal
+// on the random stream; 0 = always in their own lanes: the measurement builds' control)
+constexpr int kEtcPlanarShared = Tune::kEtcPlanarShared;
+constexpr int kEtcPlanarSlots = kEtcPlanarShared > 0 ? kEtcPlanarShared : 1;
+struct alignas(16) EtcPlanarSlab { uint32_t coef[kEtcPlanarSlots][8]; uint32_t texel[kEtcPlanarSlots * 16]; };	// texel[16 * b + 4 * y + x]
 DH EtcPlanarSlab &etc_planar_slab() { __shared__ EtcPlanarSlab slabs[4]; return slabs[threadIdx.x >> 6]; }
 DH void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -231,9 +229,9 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 			if (!(mode_mask & need)) return false;
 		}
 	}
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_PLANAR_IN_LANE)
+#if defined(__HIP_DEVICE_COMPILE__)
 	uint64_t planar_owners = 0;
-	const bool planar_shared = KIND != 0 && etc_planar_shared(mode_planar, planar_owners);	// wave-uniform
+	const bool planar_shared = KIND != 0 && kEtcPlanarShared > 0 && etc_planar_shared(mode_planar, planar_owners);	// wave-uniform
 	if (mode_planar && !planar_shared) {
 #else
 	if (mode_planar) {
@@ -306,7 +304,7 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 		if (!opaque) { pal0[2] = 0u; pal1[2] = 0u; }
 	}
 	etc_texels(word, flip, pal0, pal1, d);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DETEXHIP_EXP_PLANAR_IN_LANE)
+#if defined(__HIP_DEVICE_COMPILE__)
 	// the few planar blocks of this wave went through the palette path with meaningless palettes; their texels come now
 	if (KIND != 0 && planar_shared) etc_planar_wave<ALPHA>(mode_planar, planar_owners, W, word, d);
 #endif

@@ -222,11 +222,7 @@ DH bool rgtc_channel_s16(uint32_t w0, uint32_t w1, uint32_t (&pairs)[8]) {
 
 struct DecRGTC1 {
 	static constexpr int kBlockBytes = 8, kPixelBytes = 1, kNative = kNatR8;
-#if defined(DETEXHIP_EXP_RGTC1_GROUP)
-	static constexpr int kLaneBlocks = DETEXHIP_EXP_RGTC1_GROUP;
-#else
-	static constexpr int kLaneBlocks = 4;	// blocks per lane in the linear kernel (kernels.h: decode_linear_grouped)
-#endif
+	static constexpr int kLaneBlocks = Tune::kRgtc1LaneBlocks;	// blocks per lane in the linear kernel (kernels.h: decode_linear_grouped)
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[4]) {
 		rgtc_channel_u8(blk.x, blk.y, d);
 		return true;

@@ -30,6 +30,7 @@
 #include "ab/variant_tile4x4.h"
 #include "ab/decode_bptc_r01.h"
 #include "ab/kernels_sorted.h"
+#include "ab/kernels_persistent.h"
 #endif
 
 using namespace detexhip;
@@ -97,45 +98,11 @@ template <class Dec, class F> hipError_t with_epilogue(int epi, F &&fn) {
 // decoders whose throughput kernels carry wave-uniform specialisations use the plain form in the kernels that
 // are not on the throughput path (clipped geometry, mip levels), to bound code size
 template <class Dec> struct PlainDecoder { using type = Dec; };
-#if !defined(DETEXHIP_EXP_BC7_PLAIN)
-template <> struct PlainDecoder<DecBPTC> { using type = DecBPTCPlain; };
-#endif
-
-// workgroups that are resident at once on the current device for this kernel (cached per kernel)
-template <class K> uint32_t resident_workgroups(K kernel) {
-	static std::atomic<uint32_t> cached{ 0 };
-	uint32_t v = cached.load(std::memory_order_relaxed);
-	if (v == 0) {
-		int per_cu = 0, cus = 0, dev = 0;
-		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0 || cus <= 0)
-			v = 2048;
-		else
-			v = (uint32_t)per_cu * (uint32_t)cus;
-		cached.store(v, std::memory_order_relaxed);
-	}
-	return v;
-}
-// one workgroup per 256-block tile, or (PersistentTiles) twice as many workgroups as are resident at once, each looping
-// over tiles.  Measured on BC7 8192^2 (stream U / C, 7 workgroups per CU resident, same box): exactly the resident
-// count 59.7 / 52.9 us, a grid balanced to equal tile counts 62.6 / 55.8, 1.5x 60.1 / 52.0, 2x 58.8 / 50.7, 3x 58.7 / 51.1,
-// 5x 58.5 / 51.1, 9x (one tile each, the table copy paid per tile) 62.0 / 53.5: a second round lets the dispatcher even
-// out the CUs, more rounds only add table copies.  Decoders without sizeable tables are 1-20 % SLOWER on a persistent
-// grid than with one workgroup per tile (measured for all of them), so only BC7 uses one.
-template <class Dec, bool BLOCK_MAJOR = false, class K> uint32_t grid_for(K kernel, uint32_t tiles) {
-	if constexpr (BLOCK_MAJOR ? PersistentBlocks<Dec>::value : PersistentTiles<Dec>::value) {
-		// (measurement builds only: DETEXHIP_TILES_PER_WORKGROUP=n makes the grid tiles / n instead)
-		static const uint32_t tiles_per_wg = [] { const char *e = getenv("DETEXHIP_TILES_PER_WORKGROUP"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 0u; }();
-		if (tiles_per_wg) return (tiles + tiles_per_wg - 1u) / tiles_per_wg;
-		const uint32_t grid = 2u * resident_workgroups(kernel);
-		return tiles < grid ? tiles : grid;
-	}
-	return tiles;
-}
+template <> struct PlainDecoder<DecBPTCT<true>> { using type = DecBPTCPlain; };
 
 #ifdef DETEXHIP_AB_VARIANTS
 #include "ab/ab_dispatch.h"
-constexpr int kMaxVariant = 5;
+constexpr int kMaxVariant = 7;
 #else
 constexpr int kMaxVariant = 0;
 #endif
@@ -157,7 +124,7 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 #endif
 		// narrow pixels (RGTC1, SIGNED_RGTC1): several blocks per lane, so that a store instruction covers a longer run
 		constexpr int kRow = EpilogueOf<Dec, EPI>::kRowDwords, kGroup = kRow * LaneBlocks<Dec>::value <= 4 ? LaneBlocks<Dec>::value : 1;
-		if constexpr (kGroup > 1 && !PersistentTiles<Dec>::value) {
+		if constexpr (kGroup > 1) {
 			if (g.wb % kGroup == 0 && (reinterpret_cast<uintptr_t>(px) | g.pitch) % (4u * kRow * kGroup) == 0) {
 				hipLaunchKernelGGL((decode_linear_grouped<Dec, EPI, true, kGroup>), dim3((n / kGroup + 255u) / 256u), dim3(256), 0, g.stream,
 					g.blocks, px, g.wb, n, g.pitch, g.status);
@@ -165,8 +132,7 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 			}
 		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
-		auto kernel = decode_linear<Dec, EPI, true>;
-		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec>(kernel, tiles)), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+		hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
 	} else {
 		hipLaunchKernelGGL((decode_linear_clipped<typename PlainDecoder<Dec>::type, EPI>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n,
 			g.width, g.height, g.pitch, g.status);
@@ -183,12 +149,10 @@ template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 	const uint32_t tiles = (uint32_t)((a.n + 255u) / 256u);
 	uint8_t *px = static_cast<uint8_t *>(a.pixels);
 	if (a.checked) {
-		auto kernel = decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>;
-		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec, true>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
-			a.flags, a.ok, a.status);
+		hipLaunchKernelGGL((decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n,
+			a.mode_mask, a.flags, a.ok, a.status);
 	} else {
-		auto kernel = decode_blocks<Dec, EPI, false>;
-		hipLaunchKernelGGL(kernel, dim3(grid_for<Dec, true>(kernel, tiles)), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		hipLaunchKernelGGL((decode_blocks<Dec, EPI, false>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	}
 	return hipGetLastError();
@@ -226,9 +190,8 @@ template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks,
 	// 1024-lane workgroups, eight loads in flight per lane; every further workgroup adds serialised global atomics at the end
 	// (kernels_extra.h).  Measured, 4 Mi / 16 Mi blocks, us per call incl. the memset: BC7 grid 96: 15.3, 128: 14.0 / 40.5,
 	// 192: 14.0, 256: 14.3 / 42.2, 384: 14.7; ETC2 128: 11.8 / 32.3, 192: 10.6, 256: 10.4 / 24.4, 384: 11.4
-	// (round 2 began at 22.0 and 18.0 with 256 workgroups of 256 lanes).  DETEXHIP_HISTOGRAM_GRID overrides (measurement knob).
-	static const unsigned forced_grid = [] { const char *e = getenv("DETEXHIP_HISTOGRAM_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
-	const unsigned max_grid = forced_grid ? forced_grid : (DWORDS == 2 ? 256u : 192u);
+	// (round 2 began at 22.0 and 18.0 with 256 workgroups of 256 lanes).
+	const unsigned max_grid = DWORDS == 2 ? 256u : 192u;
 	const size_t tiles = (n + kHistogramLanes - 1) / kHistogramLanes;
 	const unsigned grid = (unsigned)(tiles < max_grid ? tiles : max_grid);
 	hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS>), dim3(grid), dim3(kHistogramLanes), 0, stream, static_cast<const uint32_t *>(blocks),
@@ -417,8 +380,12 @@ bool context_ready() {
 int current_variant() {
 	ThreadContext &c = t_ctx;
 	if (c.variant < 0) {
-		const char *env = getenv("DETEXHIP_VARIANT");
+#ifdef DETEXHIP_AB_VARIANTS
+		const char *env = getenv("DETEXHIP_VARIANT");	// measurement build only
 		c.variant = env ? atoi(env) : 0;
+#else
+		c.variant = 0;
+#endif
 		if (c.variant < 0 || c.variant > kMaxVariant) c.variant = 0;
 	}
 	return c.variant;

@@ -10,6 +10,7 @@
 // variants are tested against.
 #pragma once
 #include <stdint.h>
+#include "tune.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -165,6 +166,19 @@ DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
 	const uint32_t k0 = bit_to_mask(pos, 5), k1 = bit_to_mask(pos, 6);
 	const uint32_t x_lo = bfi(k1, b.w[2], b.w[0]), x_mid = bfi(k1, b.w[3], b.w[1]), x_hi = b.w[2] & ~k1;
 	return __builtin_amdgcn_alignbit(bfi(k0, x_hi, x_mid), bfi(k0, x_mid, x_lo), pos & 31u);
+}
+
+// Issue priority of this wave among the waves of its SIMD (s_setprio, 0..3; higher is served first).  STAGE is the
+// position in the decode (0 = block arrived, 1 = endpoints done, 2 = second half of the texels), POLICY the Tune
+// constant: 0 = leave the hardware's arbitration alone; 1 = priority rises with progress, so waves close to their
+// stores finish first and completions -- and with them the store traffic -- spread out instead of arriving in
+// generations; 2 = only the last stage is raised; 3 = the reverse of 1 (control experiment).
+template <int POLICY, int STAGE> DH void stage_priority() {
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (POLICY == 1) __builtin_amdgcn_s_setprio(STAGE + 1);
+	else if constexpr (POLICY == 2) { if constexpr (STAGE == 2) __builtin_amdgcn_s_setprio(3); }
+	else if constexpr (POLICY == 3) __builtin_amdgcn_s_setprio(2 - STAGE);
+#endif
 }
 
 // ---- workgroup-shared lookup tables in LDS ---------------------------------------------------------

@@ -24,14 +24,6 @@
 
 namespace detexhip {
 
-// decoders with sizeable LDS tables (Dec::kPersistent) run on a grid that just fills the chip, each workgroup looping
-// over tiles of 256 blocks, so the table copy at kernel entry is paid once per resident workgroup
-template <class Dec, class = void> struct PersistentTiles { static constexpr bool value = false; };
-template <class Dec> struct PersistentTiles<Dec, std::enable_if_t<Dec::kPersistent>> { static constexpr bool value = true; };
-// the same choice for the block-major kernel (Dec::kPersistentBlocks)
-template <class Dec, class = void> struct PersistentBlocks { static constexpr bool value = false; };
-template <class Dec> struct PersistentBlocks<Dec, std::enable_if_t<Dec::kPersistentBlocks>> { static constexpr bool value = true; };
-
 // waves per SIMD the register allocation must leave room for (Dec::kWavesPerSimd; default: no constraint)
 template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
 template <class Dec> struct WavesPerSimd<Dec, std::enable_if_t<(Dec::kWavesPerSimd > 0)>> { static constexpr int value = Dec::kWavesPerSimd; };
@@ -294,13 +286,13 @@ DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint3
 		uint32_t (&o)[4 * EpilogueOf<Dec, EPI>::kRowDwords]) {
 	constexpr int P = Dec::kPixelBytes;
 	uint32_t d[4 * P];
-#if defined(DETEXHIP_EXP_NOCOMPUTE)	// measurement build: memory traffic without the decode
 	bool ok = true;
+	if constexpr (Tune::kNoCompute) {	// measurement build: memory traffic without the decode
 #pragma unroll
-	for (int k = 0; k < 4 * P; k++) d[k] = (k & 1) ? blk.y : blk.x;
-#else
-	const bool ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
-#endif
+		for (int k = 0; k < 4 * P; k++) d[k] = (k & 1) ? blk.y : blk.x;
+	} else {
+		ok = Dec::template decode<CHECKED>(blk, mode_mask, flags, d);
+	}
 	EpilogueOf<Dec, EPI>::apply(d, o);
 	// texture.c:125-128: a failed block is zero-filled in the TARGET format (not "converted zeros": X / alpha stay 0).
 	// Decoders that already deliver zeros for a failed block (Dec::kZeroOnFailure) skip this when the epilogue maps zeros to
@@ -317,72 +309,51 @@ DH bool decode_block(const void *blocks, uint32_t i, uint32_t mode_mask, uint32_
 		uint32_t (&o)[4 * EpilogueOf<Dec, EPI>::kRowDwords]) {
 	return decode_word<Dec, EPI, CHECKED>(load_block<Dec>(blocks, i), mode_mask, flags, o);
 }
-#if defined(DETEXHIP_EXP_NOSTORE)	// measurement build: the decode without its stores (the condition is practically never true)
-#define DETEXHIP_STORE_IF(o) if ((o)[0] == 0x9E3779B9u && (o)[1] == 0x7F4A7C15u)
-#else
-#define DETEXHIP_STORE_IF(o)
-#endif
+// always true in the product build; the "decode without its stores" measurement build makes it practically never true
+DH bool stores_enabled(const uint32_t *o) {
+	if constexpr (Tune::kNoStore) return o[0] == 0x9E3779B9u && o[1] == 0x7F4A7C15u;
+	else return true;
+}
 
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
-// One workgroup per tile of 256 consecutive blocks -- except for decoders with sizeable LDS tables (PersistentTiles:
-// BC7), whose workgroups decode tiles blockIdx.x, blockIdx.x + gridDim.x, ... on a grid that just fills the chip.
-// Per-lane LDS rows need no barrier between tiles: a lane only reads what it wrote.
+// One workgroup per tile of 256 consecutive blocks, dispatched by the hardware.  (A persistent grid -- workgroups looping
+// over tiles, tables copied once per resident workgroup, next tile's block prefetched -- measured 1-20 % slower for every
+// format, BC7 included once its tables had shrunk: DESIGN.md section 5; that kernel lives in ab/kernels_persistent.h.)
 template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
 		uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
-	// First block: persistent grids (measurement builds) request it BEFORE the table copy and wait for it after the barrier;
-	// one-tile workgroups load it after the barrier, as in round 1 -- requesting it earlier made the workgroup's
-	// barrier wait for its slowest wave's HBM load (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 against the round-1
-	// library in the same run).  Loads are unconditional, with the index clamped into the stream: a load under a branch
-	// makes the compiler wait for it at the end of the branch.
-	const uint32_t first = blockIdx.x * 256u + threadIdx.x;
-	const uint32_t first_clamped = first < n_blocks ? first : n_blocks - 1u;
-	Word blk;
-	if constexpr (PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
-	if constexpr (!PersistentTiles<Dec>::value) blk = reinterpret_cast<const Word *>(blocks)[first_clamped];
+	// The block is loaded AFTER the table copy's barrier: requested before it, the barrier waits for the workgroup's slowest
+	// HBM round trip (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 in the same run).  The load is unconditional, with
+	// the index clamped into the stream: a load under a branch makes the compiler wait for it at the end of the branch.
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	Word blk = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
 	pin_block(blk);
-	auto decode_tile = [&](uint32_t tile, const Word &cur) {
-		const uint32_t i = tile * 256u + threadIdx.x;
-		if constexpr (ROW == 8 && NT) {
-			// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
-			const bool live = i < n_blocks;
-			uint32_t o[4 * ROW];
-			bool ok = true;
-			if (live) ok = decode_word<Dec, EPI, false>(cur, 0xFFFFFFFFu, 0u, o);
-			DETEXHIP_STORE_IF(o)
+	if constexpr (ROW == 8 && NT) {
+		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
+		const bool live = i < n_blocks;
+		uint32_t o[4 * ROW];
+		bool ok = true;
+		if (live) ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+		if (stores_enabled(o))
 			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
-			if (live) raise_status(!ok, status);
-		} else {
-			if (i >= n_blocks) return;
-			uint32_t o[4 * ROW];
-			const bool ok = decode_word<Dec, EPI, false>(cur, 0xFFFFFFFFu, 0u, o);
-			uint32_t by, bx;
-			split_index(i, width_in_blocks, by, bx);
-			uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
-			DETEXHIP_STORE_IF(o) {
-#pragma unroll
-				for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
-			}
-			raise_status(!ok, status);
-		}
-	};
-	if constexpr (!PersistentTiles<Dec>::value) {
-		decode_tile(blockIdx.x, blk);			// one workgroup per tile
+		if (live) raise_status(!ok, status);
 	} else {
-		// software pipeline over the workgroup's tiles: the next tile's block is requested before this one is decoded
-		const uint32_t n_tiles = (n_blocks + 255u) >> 8;
-		for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-			const Word cur = blk;
-			const uint32_t i_next = (tile + gridDim.x) * 256u + threadIdx.x;
-			blk = reinterpret_cast<const Word *>(blocks)[i_next < n_blocks ? i_next : n_blocks - 1u];	// requested now ...
-			decode_tile(tile, cur);
-			pin_block(blk);											// ... waited for after this tile
+		if (i >= n_blocks) return;
+		uint32_t o[4 * ROW];
+		const bool ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+		uint32_t by, bx;
+		split_index(i, width_in_blocks, by, bx);
+		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
+		if (stores_enabled(o)) {
+#pragma unroll
+			for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
 		}
+		raise_status(!ok, status);
 	}
 }
 
@@ -419,7 +390,7 @@ __global__ __launch_bounds__(256) void decode_linear_grouped(const void *__restr
 	uint32_t by, bx;
 	split_index(first, width_in_blocks, by, bx);
 	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
-	DETEXHIP_STORE_IF(o[0]) {
+	if (stores_enabled(o[0])) {
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			uint32_t row[ROW * G];
@@ -509,14 +480,12 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
-	const uint32_t n_tiles = PersistentBlocks<Dec>::value ? (n_blocks + 255u) >> 8 : blockIdx.x + 1u;	// see decode_linear
-	// (requesting the next tile's block ahead, as decode_linear does, measured no gain here: 63.6-64.0 vs 62.4-63.0 us on BC7)
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const uint32_t i = tile * 256u + threadIdx.x;
+	{
+		const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 		const bool live = i < n_blocks;
 		if constexpr (ROW == 1) {
 			// 16 bytes per block: the wave's output is already one contiguous 1 KiB run per store instruction
-			if (!live) continue;
+			if (!live) return;
 			uint32_t o[4];
 			const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
 			__builtin_nontemporal_store(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
@@ -551,6 +520,12 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 			const uint32_t first = i - lane;						// the wave's first block
 			const uint32_t vectors = (first < n_blocks ? min(64u, n_blocks - first) : 0u) * ROW;
 			v4 *out = reinterpret_cast<v4 *>(pixels) + (uint64_t)first * ROW;
+			if constexpr (OWN) {
+				// the staging slots are OTHER lanes' decoder rows: every lane of the wave must be done with its decode
+				// (all of its row reads retired) before the first staging store lands there
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
 #pragma unroll
 			for (int p = 0; p < PASSES; p++) {
 				if (live && (PASSES == 1 || lane / GROUP == (uint32_t)p)) {
@@ -570,7 +545,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(c
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 			}
-			if (!live) continue;
+			if (!live) return;
 			if (ok_out) ok_out[i] = ok ? 1 : 0;
 			raise_status(!ok, status);
 		}

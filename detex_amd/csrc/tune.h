@@ -1,0 +1,38 @@
+// tune.h -- the handful of constants the measurement builds of DESIGN.md section 5 vary.
+//
+// The product library is compiled with ProductTune, and this file holds the ONLY preprocessor switch of the
+// measurement builds: tools/build_exp_libs.sh writes a small header that derives `Tune` from ProductTune with one or two
+// members overridden and names it in DETEXHIP_TUNE_HEADER.  Kernels and decoders read `Tune::k...` in `if constexpr`
+// / template arguments, so the product translation unit carries no measurement `#if`.
+#pragma once
+
+namespace detexhip {
+
+struct ProductTune {
+	// decode without its stores / stores without the decode (profiles/*/compute_vs_memory.jsonl)
+	static constexpr bool kNoStore = false, kNoCompute = false;
+	// BC7: register budget in waves per SIMD (80 VGPRs, no spill), the wave-uniform per-record copies of the decoder, the
+	// block-major exchange staged in the decoder's own (dead) lane rows, and the s_setprio staging of the decode (0 = off,
+	// 1 = priority rises with the wave's progress)
+	static constexpr int kBc7WavesPerSimd = 6;
+	static constexpr bool kBc7Uniform = true;
+	static constexpr int kBc7UniformTexelGroup = 4;	// subset rows requested together in the per-record copies (1 in the mixed-mode path)
+	static constexpr bool kBc7OwnStage = true;
+	static constexpr int kBc7Prio = 0;
+	// BC6H: the same priority staging
+	static constexpr int kBc6hPrio = 0;
+	// v_bitop3_b32 masks pinned into VGPRs (an SGPR source halves the issue rate of a full-rate VALU op)
+	static constexpr bool kMasksInVgprs = true;
+	// RGTC1: blocks per lane in the linear kernel
+	static constexpr int kRgtc1LaneBlocks = 4;
+	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
+	static constexpr int kEtcPlanarShared = 8;
+};
+
+#if defined(DETEXHIP_TUNE_HEADER)
+#include DETEXHIP_TUNE_HEADER	// measurement build: `struct Tune : ProductTune { ...overrides... };`
+#else
+using Tune = ProductTune;
+#endif
+
+}  // namespace detexhip

@@ -1,6 +1,6 @@
 """Parity of the rejected A/B kernels.  They are NOT part of the product library: build
 them with `make lib-ab` and run
-    DETEXHIP_LIB=detex_amd/lib/libdetexhip_ab.so python -m pytest tests/test_ab_variants.py -m gpu
+    DETEXHIP_LIB=build/explib/libdetexhip_ab.so python -m pytest tests/test_ab_variants.py -m gpu
 Without DETEXHIP_LIB pointing at an A/B build this module is skipped."""
 import os
 

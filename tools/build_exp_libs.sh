@@ -1,25 +1,47 @@
 #!/bin/bash
-# measurement builds of libdetexhip (never shipped): bash tools/build_exp_libs.sh nostore nocompute pad8192 sgprconst rgtc1g2 planarinlane bc7stage ...
+# Measurement builds of libdetexhip into build/explib/ (never shipped with the product; the package directory holds the product library only):  bash tools/build_exp_libs.sh nostore nocompute prio1 ab_prio1 ...
+# Each name maps to overrides of detex_amd/csrc/tune.h's ProductTune; a generated header carries them and is named in
+# -DDETEXHIP_TUNE_HEADER (the one preprocessor switch of the measurement builds).  Names starting with ab_ also get
+# -DDETEXHIP_AB_VARIANTS (the rejected A/B kernels, bench.py --variant N / DETEXHIP_VARIANT=N), so knobs and variants combine.
+#   nostore / nocompute     decode without its stores / stores without the decode
+#   wavesN                  BC7 register budget (waves per SIMD)
+#   plain                   BC7 without the wave-uniform per-record copies
+#   grpN                    BC7: subset rows requested together in the per-record copies
+#   bc7stage                block-major BC7 with the separate 17 KiB staging array
+#   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
+#   sgprconst               v_bitop3 masks left in SGPRs
+#   rgtc1gN                 RGTC1 blocks per lane
+#   planarN                 ETC2: most planar blocks per wave decoded cooperatively (0 = always in-lane)
+#   several joined by '+':  nostore+prio1
 set -e
 cd "$(dirname "$0")/.."
+mkdir -p build/tune build/explib
 for v in "$@"; do
-  case $v in
-    nostore) D=-DDETEXHIP_EXP_NOSTORE ;;
-    nocompute) D=-DDETEXHIP_EXP_NOCOMPUTE ;;
-    pad*) D=-DDETEXHIP_EXP_LDS_PAD=${v#pad} ;;
-    waves*) D=-DDETEXHIP_EXP_BC7_WAVES=${v#waves} ;;
-    persistent) D=-DDETEXHIP_EXP_BC7_PERSISTENT ;;             # BC7 (linear and block-major) on the persistent grid of round 2's first half
-    plain) D=-DDETEXHIP_EXP_BC7_PLAIN ;;
-    plain_persistent) D="-DDETEXHIP_EXP_BC7_PLAIN -DDETEXHIP_EXP_BC7_PERSISTENT" ;;
-    sgprconst) D=-DDETEXHIP_EXP_SGPR_CONST ;;                 # v_bitop3 masks left in SGPRs (BC7 / BC6H)
-    rgtc1g*) D=-DDETEXHIP_EXP_RGTC1_GROUP=${v#rgtc1g} ;;      # RGTC1 blocks per lane (1 = the one-block kernel)
-    planar[0-9]*) D=-DDETEXHIP_EXP_PLANAR_SHARED=${v#planar} ;; # most planar blocks per wave decoded cooperatively (default 8)
-    planarinlane) D=-DDETEXHIP_EXP_PLANAR_IN_LANE ;;          # ETC2 planar blocks always decoded in their own lanes
-    bc7stage) D=-DDETEXHIP_EXP_BC7_SEPARATE_STAGE ;;          # block-major BC7 with the separate 17 KiB staging array
-    *) D="$EXP_DEFS" ;;
-  esac
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $D -Wall -Wno-unused-function \
-    -o detex_amd/lib/libdetexhip_exp_$v.so detex_amd/csrc/detexhip.hip detex_amd/csrc/ktx_loader.cpp &
+  body=""; extra=""
+  name=$v
+  case $v in ab_*) extra=-DDETEXHIP_AB_VARIANTS; v=${v#ab_} ;; esac
+  IFS='+' read -ra parts <<< "$v"
+  for k in "${parts[@]}"; do
+    case $k in
+      base) ;;
+      nostore) body+="static constexpr bool kNoStore = true; " ;;
+      nocompute) body+="static constexpr bool kNoCompute = true; " ;;
+      waves*) body+="static constexpr int kBc7WavesPerSimd = ${k#waves}; " ;;
+      grp*) body+="static constexpr int kBc7UniformTexelGroup = ${k#grp}; " ;;
+      plain) body+="static constexpr bool kBc7Uniform = false; " ;;
+      bc7stage) body+="static constexpr bool kBc7OwnStage = false; " ;;
+      prio*) body+="static constexpr int kBc7Prio = ${k#prio}; " ;;
+      bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;
+      sgprconst) body+="static constexpr bool kMasksInVgprs = false; " ;;
+      rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
+      planar*) body+="static constexpr int kEtcPlanarShared = ${k#planar}; " ;;
+      *) echo "unknown knob $k" >&2; exit 2 ;;
+    esac
+  done
+  hdr=$PWD/build/tune/tune_$name.h
+  echo "struct Tune : ProductTune { $body};" > "$hdr"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $extra "-DDETEXHIP_TUNE_HEADER=\"$hdr\"" \
+    -Wall -Wno-unused-function -Wno-pass-failed -o build/explib/libdetexhip_exp_$name.so detex_amd/csrc/detexhip.hip detex_amd/csrc/ktx_loader.cpp &
 done
 wait
-ls -la detex_amd/lib
+ls -la build/explib

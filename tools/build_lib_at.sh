@@ -1,11 +1,11 @@
 #!/bin/bash
-# build the library as it was at a given commit into detex_amd/lib/libdetexhip_<tag>.so (same-run comparisons):
+# build the library as it was at a given commit into build/explib/libdetexhip_<tag>.so (same-run comparisons):
 #   bash tools/build_lib_at.sh 0ebf32e r01      # the round-1 library used by tools/gpu_cmp_r01.sh
 #   bash tools/build_lib_at.sh HEAD prev        # the last commit, against uncommitted changes
 set -e
 cd "$(dirname "$0")/.."
-COMMIT=$1; TAG=$2; TMP=$(mktemp -d)
+COMMIT=$1; TAG=$2; TMP=$(mktemp -d); mkdir -p build/explib
 git archive "$COMMIT" detex_amd/csrc include | tar -x -C "$TMP"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wall -Wno-unused-function -Wno-pass-failed \
-  -o detex_amd/lib/libdetexhip_$TAG.so "$TMP/detex_amd/csrc/detexhip.hip" "$TMP/detex_amd/csrc/ktx_loader.cpp"
-rm -rf "$TMP"; ls -la detex_amd/lib/libdetexhip_$TAG.so
+  -o build/explib/libdetexhip_$TAG.so "$TMP/detex_amd/csrc/detexhip.hip" "$TMP/detex_amd/csrc/ktx_loader.cpp"
+rm -rf "$TMP"; ls -la build/explib/libdetexhip_$TAG.so

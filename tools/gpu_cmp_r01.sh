@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-run comparison of the round-1 library (built from commit 0ebf32e into detex_amd/lib/libdetexhip_r01.so) with the current one
+# same-run comparison of the round-1 library (built from commit 0ebf32e into build/explib/libdetexhip_r01.so) with the current one
 export TMPDIR=/tmp
 OUT=gpurun_out/cmp_r01; mkdir -p $OUT; ROOT=$(pwd)
 FM=BPTC,ETC2,ETC2_EAC,ETC2_PUNCHTHROUGH,SIGNED_RGTC2,SIGNED_RGTC1,EAC_SIGNED_R11,EAC_R11,RGTC2,RGTC1,BPTC_FLOAT,BPTC_SIGNED_FLOAT,BC1,BC3

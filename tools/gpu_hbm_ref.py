@@ -1,27 +1,40 @@
-"""Reference points for the HBM roofline on this box: what plain fill / copy kernels of the same footprint reach.
-(bytes moved per second; copy counts read + write)"""
+"""Reference points for the HBM roofline on this box, and the data-dependence question of DESIGN.md section 8:
+write-only fills with the decode kernels' store shape (tools/ubench/hbm_ref.hip) for seven data patterns at sizes on both
+sides of the 256 MiB Infinity Cache, non-temporal and ordinary stores, plus 16-byte-vector copies.
+usage: python tools/gpu_hbm_ref.py [out.jsonl]      (one JSON line per measurement, a table on stderr)"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-def t(fn, n=50):
-    for _ in range(5): fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
-for mib in (256, 1024):
+import hbmref
+
+out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+def emit(row):
+    line = json.dumps(row)
+    print(line, flush=True)
+    if out:
+        out.write(line + "\n"); out.flush()
+
+for mib in (128, 256, 512, 1024, 4096):
     nbytes = mib << 20
-    a = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda"); b = torch.empty_like(a)
-    s = t(lambda: a.fill_(7)); print("fill  %4d MiB: %7.1f us  %.2f TB/s written" % (mib, s * 1e6, nbytes / s / 1e12))
-    s = t(lambda: torch.cuda.memset if False else a.zero_()); print("zero  %4d MiB: %7.1f us  %.2f TB/s written" % (mib, s * 1e6, nbytes / s / 1e12))
-    s = t(lambda: b.copy_(a)); print("copy  %4d MiB: %7.1f us  %.2f TB/s read+written" % (mib, s * 1e6, 2 * nbytes / s / 1e12))
-# hipMemsetD32Async with a zero and a non-zero pattern (is the fast "zero" a tuned kernel or a property of zeros?)
-import ctypes
-hip = ctypes.CDLL("libamdhip64.so")
-hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    launches = 60 if mib <= 512 else (30 if mib <= 1024 else 10)
+    for nt in (True, False):
+        for pat in sorted(hbmref.PATTERNS):
+            if not nt and pat not in (0, 2):
+                continue
+            gbps, us = hbmref.fill_GBps(nbytes, pat, nt, launches, buf)
+            emit({"op": "fill", "MiB": mib, "pattern": pat, "pattern_name": hbmref.PATTERNS[pat], "nontemporal": nt, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
+    del buf
+    torch.cuda.empty_cache()
 for mib in (256, 1024):
-    nbytes = mib << 20
-    a = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda")
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for val in (0, 0x12345678):
-        s = t(lambda: hip.hipMemsetD32Async(a.data_ptr(), val, nbytes // 4, st))
-        print("hipMemsetD32Async(0x%08X) %4d MiB: %7.1f us  %.2f TB/s written" % (val, mib, s * 1e6, nbytes / s / 1e12))
+    for nt in (True, False):
+        gbps, us = hbmref.copy_GBps(mib << 20, nt, 30)
+        emit({"op": "copy", "MiB": mib, "nontemporal": nt, "us": round(us, 1), "TBps_read_plus_written": round(gbps / 1e3, 3)})
+# torch's own fill / zero / copy for comparison with round 1's table
+for mib in (256, 1024):
+    n = (mib << 20) // 4
+    a = torch.empty(n, dtype=torch.int32, device="cuda"); b = torch.empty_like(a)
+    for name, fn, mult in (("torch fill_(7)", lambda: a.fill_(7), 1), ("torch zero_()", lambda: a.zero_(), 1), ("torch copy_", lambda: b.copy_(a), 2)):
+        us = hbmref.time_us(fn, 30)
+        emit({"op": name, "MiB": mib, "us": round(us, 1), "TBps": round(mult * (mib << 20) / (us * 1e-6) / 1e12, 3)})
+    del a, b

@@ -21,11 +21,11 @@ echo "== epilogue targets"; for spec in BC1:BGRA8 BC1:RGB8 RGTC1:BGRX8 EAC_RG11:
 echo "== N=2 code path over gloo on one GPU (plumbing, not a measurement)"
 DETEX_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_n2_gloo_one_gpu.json 2>> $OUT/bench.err; cut -c1-300 $OUT/bench_n2_gloo_one_gpu.json
 echo "== BC7 / BC6H old-vs-new (A/B build)"
-DETEXHIP_LIB=$ROOT/detex_amd/lib/libdetexhip_ab.so DETEXHIP_VARIANT=4 timeout 300 python tools/gpu_time.py BPTC U,M,C linear 8192 r01_decoder_variant4 2>>$OUT/bench.err | tee -a $OUT/bc7_ab.jsonl | cut -c1-140
+DETEXHIP_LIB=$ROOT/build/explib/libdetexhip_ab.so DETEXHIP_VARIANT=4 timeout 300 python tools/gpu_time.py BPTC U,M,C linear 8192 r01_decoder_variant4 2>>$OUT/bench.err | tee -a $OUT/bc7_ab.jsonl | cut -c1-140
 timeout 300 python tools/gpu_time.py BPTC U,M,C linear 8192 r02_decoder 2>>$OUT/bench.err | tee -a $OUT/bc7_ab.jsonl | cut -c1-140
-DETEXHIP_LIB=$ROOT/detex_amd/lib/libdetexhip_ab.so timeout 300 python -m pytest tests/test_ab_variants.py -m gpu -q -p no:cacheprovider 2>&1 | tail -2 | tee $OUT/pytest_ab.log
-echo "== round-1 library (commit 0ebf32e built into detex_amd/lib/libdetexhip_r01.so) vs this one, same run"
-[ -f detex_amd/lib/libdetexhip_r01.so ] && bash tools/gpu_cmp_r01.sh 2>&1 | tail -14 | tee $OUT/r01_vs_r02_same_run.txt
+DETEXHIP_LIB=$ROOT/build/explib/libdetexhip_ab.so timeout 300 python -m pytest tests/test_ab_variants.py -m gpu -q -p no:cacheprovider 2>&1 | tail -2 | tee $OUT/pytest_ab.log
+echo "== round-1 library (commit 0ebf32e built into build/explib/libdetexhip_r01.so) vs this one, same run"
+[ -f build/explib/libdetexhip_r01.so ] && bash tools/gpu_cmp_r01.sh 2>&1 | tail -14 | tee $OUT/r01_vs_r02_same_run.txt
 echo "== decode without stores / stores without decode (measurement builds)"
 for lib in libdetexhip libdetexhip_exp_nostore libdetexhip_exp_nocompute; do DETEXHIP_LIB=$ROOT/detex_amd/lib/$lib.so timeout 300 python tools/gpu_time.py BPTC,BPTC_SIGNED_FLOAT,BPTC_FLOAT,ETC2_EAC,RGTC1,BC3,BC1 U 2>>$OUT/bench.err | tee -a $OUT/compute_vs_memory.jsonl | cut -c1-130; done
 echo "== mode histograms (4 Mi and 16 Mi blocks)"; (timeout 300 python tools/bench_histogram.py 2>/dev/null; timeout 300 python tools/bench_histogram.py 4096 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120

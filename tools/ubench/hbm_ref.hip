@@ -1,0 +1,81 @@
+// tools/ubench/hbm_ref.hip -- reference points for the HBM roofline, measured on the box a bench run uses:
+// a write-only fill with the store shape of the decode kernels (four non-temporal 16-byte stores per lane, each wave
+// instruction one contiguous 1 KiB run) and a 16-byte-vector copy.  Built as tools/ubench/libhbmref.so; bench.py loads it
+// (ctypes) to report roofline.ref_fill_GBps / ref_copy_GBps beside the decode kernel, tools/gpu_hbm_ref.py sweeps sizes and
+// data patterns.  Measurement tooling: nothing here is linked into libdetexhip.so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+	x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
+	return x;
+}
+
+// PATTERN 0 zeros . 1 one constant dword . 2 uniform random dwords . 3 random, but the upper half of every second dword 0 (the
+// X component of FLOAT_RGBX16 pixels) . 4 random, constant within each 16-byte vector . 5 random bytes < 64 (few set bits)
+// . 6 random with every second BYTE zero
+template <int PATTERN> __device__ __forceinline__ v4 make_vector(uint32_t vec, uint32_t seed) {
+	if (PATTERN == 0) return v4{ 0u, 0u, 0u, 0u };
+	if (PATTERN == 1) return v4{ 0x12345678u, 0x12345678u, 0x12345678u, 0x12345678u };
+	const uint32_t a = hash32(4u * vec + seed), b = hash32(4u * vec + 1u + seed), c = hash32(4u * vec + 2u + seed), d = hash32(4u * vec + 3u + seed);
+	if (PATTERN == 2) return v4{ a, b, c, d };
+	if (PATTERN == 3) return v4{ a, b & 0xFFFFu, c, d & 0xFFFFu };
+	if (PATTERN == 4) return v4{ a, a, a, a };
+	if (PATTERN == 5) return v4{ a & 0x3F3F3F3Fu, b & 0x3F3F3F3Fu, c & 0x3F3F3F3Fu, d & 0x3F3F3F3Fu };
+	return v4{ a & 0x00FF00FFu, b & 0x00FF00FFu, c & 0x00FF00FFu, d & 0x00FF00FFu };
+}
+
+// one workgroup = 256 lanes x 4 vectors = 16 KiB, written as four wave-wide 1 KiB runs per wave (rows 4 KiB apart, like the
+// texel rows of a 1024-pixel-wide tile)
+template <int PATTERN, bool NT> __global__ __launch_bounds__(256) void fill_kernel(v4 *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint64_t i = base + (uint64_t)r * 256u + threadIdx.x;
+		if (i < n_vectors) {
+			const v4 v = make_vector<PATTERN>((uint32_t)i, seed);
+			if (NT) __builtin_nontemporal_store(v, dst + i);
+			else dst[i] = v;
+		}
+	}
+}
+
+template <bool NT> __global__ __launch_bounds__(256) void copy_kernel(v4 *__restrict__ dst, const v4 *__restrict__ src, uint64_t n_vectors) {
+	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
+	v4 v[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint64_t i = base + (uint64_t)r * 256u + threadIdx.x;
+		v[r] = NT ? __builtin_nontemporal_load(src + (i < n_vectors ? i : n_vectors - 1u)) : src[i < n_vectors ? i : n_vectors - 1u];
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint64_t i = base + (uint64_t)r * 256u + threadIdx.x;
+		if (i < n_vectors) { if (NT) __builtin_nontemporal_store(v[r], dst + i); else dst[i] = v[r]; }
+	}
+}
+
+extern "C" __attribute__((visibility("default"))) int hbmref_fill(void *dst, size_t bytes, int pattern, int nontemporal, uint32_t seed, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const dim3 grid((unsigned)((n + 1023u) / 1024u)), block(256);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+#define FILL(P) case P: if (nontemporal) hipLaunchKernelGGL((fill_kernel<P, true>), grid, block, 0, s, d, n, seed); \
+	else hipLaunchKernelGGL((fill_kernel<P, false>), grid, block, 0, s, d, n, seed); break;
+	switch (pattern) { FILL(0) FILL(1) FILL(2) FILL(3) FILL(4) FILL(5) FILL(6) default: return 1; }
+#undef FILL
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+extern "C" __attribute__((visibility("default"))) int hbmref_copy(void *dst, const void *src, size_t bytes, int nontemporal, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u)) return 1;
+	const dim3 grid((unsigned)((n + 1023u) / 1024u)), block(256);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (nontemporal) hipLaunchKernelGGL((copy_kernel<true>), grid, block, 0, s, static_cast<v4 *>(dst), static_cast<const v4 *>(src), n);
+	else hipLaunchKernelGGL((copy_kernel<false>), grid, block, 0, s, static_cast<v4 *>(dst), static_cast<const v4 *>(src), n);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
