@@ -158,8 +158,33 @@ def shard_rows(height_in_blocks, n_shards, shard):
     return r0.value, r1.value
 
 
+def decompress_linear_multi_device_host(fmt, host_blocks, width, height, devices, out=None, pitch=None, pixel_format=None,
+                                        width_in_blocks=None, height_in_blocks=None):
+    """detexhipDecompressTextureLinearMultiDeviceHost: numpy blocks in, numpy pixels out, one shard (and one PCIe link)
+    per entry of `devices`.  Returns (ok, pixels, wall_ms)."""
+    import numpy as np
+    lib = load()
+    lib.detexhipDecompressTextureLinearMultiDeviceHost.argtypes = [
+        ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_uint32,
+        ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
+    pf = F.native_pixel_format(fmt) if pixel_format is None else pixel_format
+    px = 1 + ((pf & 0xF00) >> 8)
+    wb = (width + 3) // 4 if width_in_blocks is None else width_in_blocks
+    hb = (height + 3) // 4 if height_in_blocks is None else height_in_blocks
+    pitch = width * px if pitch is None else pitch
+    host_blocks = np.ascontiguousarray(host_blocks)
+    if out is None:
+        out = np.empty(height * pitch, np.uint8)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    invalid, wall = ctypes.c_int(), ctypes.c_float()
+    _check(lib.detexhipDecompressTextureLinearMultiDeviceHost(
+        fmt.texture_format, host_blocks.ctypes.data_as(_vp), width, height, wb, hb, out.ctypes.data_as(_vp), pitch, pf, devs, len(devices),
+        ctypes.byref(invalid), ctypes.byref(wall)), "detexhipDecompressTextureLinearMultiDeviceHost")
+    return invalid.value == 0, out, wall.value
+
+
 def decompress_linear_multi_device(fmt, width, height, devices, host_blocks=None, device_blocks=None, pixel_format=None,
-                                   gather_device=-1):
+                                   gather_device=-1, pitch=None):
     """detexhipDecompressTextureLinearMultiDevice: one texture, len(devices) shards of block rows, one calling
     thread.  host_blocks: numpy uint8 of the whole stream (uploaded by the call) or device_blocks: one torch uint8
     tensor per shard already on its device.  Returns dict(ok, bands=[torch tensors], gathered, shards, decode_wall_ms,
@@ -173,20 +198,21 @@ def decompress_linear_multi_device(fmt, width, height, devices, host_blocks=None
     pf = F.native_pixel_format(fmt) if pixel_format is None else pixel_format
     px = 1 + ((pf & 0xF00) >> 8)
     wb, hb = (width + 3) // 4, (height + 3) // 4
+    row_pitch = width * px if pitch is None else pitch
     n = len(devices)
     shards = (Shard * n)()
     bands = []
     for g, dev in enumerate(devices):
         r0, r1 = shard_rows(hb, n, g)
         rows = max(0, min(r1 * 4, height) - r0 * 4)
-        band = torch.empty(max(rows * width * px, 16), dtype=torch.uint8, device="cuda:%d" % dev)
+        band = torch.full((max(rows * row_pitch, 16),), 0xA5, dtype=torch.uint8, device="cuda:%d" % dev)
         bands.append(band)
         shards[g].device = dev
         shards[g].d_blocks = None if device_blocks is None else device_blocks[g].data_ptr()
         shards[g].d_pixels = band.data_ptr()
     gathered = None
     if gather_device >= 0:
-        gathered = torch.empty(width * height * px, dtype=torch.uint8, device="cuda:%d" % gather_device)
+        gathered = torch.full((height * row_pitch,), 0xA5, dtype=torch.uint8, device="cuda:%d" % gather_device)
     hb_ptr = None
     if host_blocks is not None:
         host_blocks = np.ascontiguousarray(host_blocks)
@@ -194,7 +220,7 @@ def decompress_linear_multi_device(fmt, width, height, devices, host_blocks=None
     t_dec, t_gat = ctypes.c_float(), ctypes.c_float()
     torch.cuda.synchronize()
     _check(lib.detexhipDecompressTextureLinearMultiDevice(
-        fmt.texture_format, hb_ptr, width, height, wb, hb, 0, pf, shards, n, gather_device,
+        fmt.texture_format, hb_ptr, width, height, wb, hb, 0 if pitch is None else pitch, pf, shards, n, gather_device,
         None if gathered is None else gathered.data_ptr(), ctypes.byref(t_dec), ctypes.byref(t_gat)),
         "detexhipDecompressTextureLinearMultiDevice")
     return {"ok": all(s.invalid_blocks == 0 for s in shards), "bands": bands, "gathered": gathered,

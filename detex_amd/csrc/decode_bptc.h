@@ -273,13 +273,14 @@ struct Bc7Lane {
 		asm("" : "+v"(a));
 		return a;
 	}
-	// group G (four consecutive words) of the record at `address`: ONE ds_read_b128, kept whole by pinning all four
-	// dwords at the point of the read (the compiler otherwise narrows it to ds_read_b96 / ds_read2_b32 when a word is unused)
-	template <int G> static DH uint4 rec_group(uint32_t address) {
-		u32x4 v = *(const lds_u4 *)(uintptr_t)(address + 16u * G);
-		asm volatile("" : "+v"(v));
-		return uint4{ v.x, v.y, v.z, v.w };
-	}
+	// group G (four consecutive words) of the record at `address`: ONE ds_read_b128.  pin() keeps such reads whole (the
+	// compiler otherwise narrows a read to ds_read_b96 / ds_read2_b32 when a word is unused: 8 and 4 LDS cycles per wave
+	// instead of 4) and is where the wave waits for them -- so a batch of groups is requested first and pinned together.
+	typedef u32x4 Group;
+	template <int G> static DH Group rec_group(uint32_t address) { return *(const lds_u4 *)(uintptr_t)(address + 16u * G); }
+	static DH void pin(Group &a) { asm volatile("" : "+v"(a)); }
+	static DH void pin(Group &a, Group &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+	static DH void pin(Group &a, Group &b, Group &c, Group &d, Group &e) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)); }
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) {
 		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().t.part) + byte_offset);
 	}
@@ -301,10 +302,14 @@ struct Bc7Lane {
 	DH void put_subset(int s, uint4 v) { subset[s] = v; }
 	DH uint4 get_subset(uint32_t sel) const { return subset[(sel >> 12) & 3u]; }
 	static DH uint32_t rec_address(uint32_t r) { return r; }
-	template <int G> static DH uint4 rec_group(uint32_t r) {
+	typedef uint4 Group;
+	template <int G> static DH Group rec_group(uint32_t r) {
 		const uint32_t *w = kBc7RecTable.r[r].w + 4 * G;
 		return uint4{ w[0], w[1], w[2], w[3] };
 	}
+	static DH void pin(Group &) {}
+	static DH void pin(Group &, Group &) {}
+	static DH void pin(Group &, Group &, Group &, Group &, Group &) {}
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) { return kBc7PartTable.e[byte_offset / sizeof(Bc7PartEntry)]; }
 	static DH uint32_t gather(uint32_t rot) { return kBc7Gather[rot]; }
 #endif
@@ -312,30 +317,37 @@ struct Bc7Lane {
 
 // FIXED >= 0: the record is a compile-time constant (every lane of the wave is known to use record FIXED)
 template <int FIXED> struct Bc7RecReader {
+	typedef Bc7Lane::Group Group;
 	uint32_t address;
 	DH explicit Bc7RecReader(uint32_t rec_index) : address(FIXED >= 0 ? 0u : Bc7Lane::rec_address(rec_index)) {}
-	template <int G> DH uint4 group() const {
+	template <int G> DH Group group() const {
 		if constexpr (FIXED >= 0) {
 			constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
-			return uint4{ kFixed.w[4 * G], kFixed.w[4 * G + 1], kFixed.w[4 * G + 2], kFixed.w[4 * G + 3] };
+			return Group{ kFixed.w[4 * G], kFixed.w[4 * G + 1], kFixed.w[4 * G + 2], kFixed.w[4 * G + 3] };
 		} else {
 			return Bc7Lane::rec_group<G>(address);
 		}
 	}
+	// the wave waits here for the groups named (a no-op for a compile-time record)
+	template <class... Gs> DH void pin(Gs &...gs) const { if constexpr (FIXED < 0) Bc7Lane::pin(gs...); }
 };
 
-template <int FIXED, bool CHECKED>
-DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
+template <int FIXED>
+DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t (&d)[16]) {
 	constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
 	const Bc7RecReader<FIXED> L(rec_index);
-	const uint4 g_head = L.template group<F_POS_PART / 4>();	// pos_part, pb, pos_rot, rb
-	const uint4 g_part = L.template group<F_PART_BASE / 4>();	// part_base, ns, mode, two
+	typedef Bc7Lane::Group Group;
+	Group g_head = L.template group<F_POS_PART / 4>();	// pos_part, pb, pos_rot, rb
+	Group g_part = L.template group<F_PART_BASE / 4>();	// part_base, ns, mode, two
+	// requested now, waited for where the endpoint phase needs them
+	Group g_row = L.template group<F_ROW_R / 4>(), g_pos = L.template group<F_POS_R / 4>();
+	Group g_p = L.template group<F_ROW_P / 4>();		// row_p, pos_p, p_word_mask, cb
+	Group g_c = L.template group<F_AB / 4>();		// ab, up_c, down_c, pconst_rg
+	Group g_ba = L.template group<F_UP_BA / 4>();		// up_ba, down_ba, pconst_ba, set_ba
+	Group g_pi = L.template group<F_PIDX0 / 4>();		// pidx0..3
+	Group g_pj = L.template group<F_PIDX4 / 4>();		// pidx4, pidx5, ins_ones, himask0_c
+	L.pin(g_head, g_part);
 	const uint32_t mode = g_part.z;
-	if (CHECKED) {							// decompress-bptc.c:363-369
-		if (!(mode_mask & (1u << mode))) return false;
-		if (mode >= 4u && (flags & kFlagOpaqueOnly)) return false;
-		if (mode < 4u && (flags & kFlagNonOpaqueOnly)) return false;
-	}
 	Bc7Lane lane;
 	lane.put_bits(blk);
 	stage_priority<Tune::kBc7Prio, 0>();
@@ -355,43 +367,41 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	const bool any_two = FIXED >= 0 ? kFixed.w[F_TWO] != 0u : __builtin_amdgcn_ballot_w64(g_part.w != 0u) != 0;
 
 	// endpoint fields: all R, then all G, then all B, then all A (each 2*ns values), then the P-bits (:74-132)
-	const uint4 g_row = L.template group<F_ROW_R / 4>(), g_pos = L.template group<F_POS_R / 4>();
+	L.pin(g_row, g_pos);
 	const uint32_t wr = lane.field(g_row.x, g_pos.x), wg = lane.field(g_row.y, g_pos.y), wb = lane.field(g_row.z, g_pos.z);
 	const uint32_t wa = wave_alpha ? lane.field(g_row.w, g_pos.w) : 0u;
-	const uint4 g_p = L.template group<F_ROW_P / 4>();		// row_p, pos_p, p_word_mask, cb
+	L.pin(g_p, g_c, g_ba, g_pi, g_pj);
 	const uint32_t pw = lane.field(g_p.x, g_p.y) & g_p.z;
-	const uint4 g_c = L.template group<F_AB / 4>();			// ab, up_c, down_c, pconst_rg
-	const uint4 g_ba = L.template group<F_UP_BA / 4>();		// up_ba, down_ba, pconst_ba, set_ba
-	const uint4 g_pi = L.template group<F_PIDX0 / 4>();		// pidx0..3
-	const uint4 g_pj = L.template group<F_PIDX4 / 4>();		// pidx4, pidx5, ins_ones, himask0_c
 	const uint32_t cb = g_p.w, ab = g_c.x;
 	const uint32_t pidx[6] = { g_pi.x, g_pi.y, g_pi.z, g_pi.w, g_pj.x, g_pj.y };
-	uint32_t x_rg[6], x_ba[6];
 	uint32_t off = 0u, offa = 0u;
-#pragma unroll
-	for (int e = 0; e < 6; e++) {
-		if ((uint32_t)(e >> 1) >= wave_subsets) break;
-		// straight into the blend's 16-bit lanes: (R, G) and (B, A)
-		const uint32_t rg = (ubfe(wg, off, cb) << 16) | ubfe(wr, off, cb);
-		uint32_t ba = ubfe(wb, off, cb);
-		if (e < 4) ba |= ubfe(wa, offa, ab) << 16;		// modes with alpha have at most two subsets; ab = 0 reads 0
-		const uint32_t pm = (uint32_t)sbfe(pw, pidx[e], 1u);			// 0 / ~0: this endpoint's P-bit
-		x_rg[e] = or3(rg << g_c.y, pk_lshr_v(g_c.z, rg), pm & g_c.w);
-		x_ba[e] = or3(pk_lshl_v(g_ba.x, ba), pk_lshr_v(g_ba.y, ba), and_or(pm, g_ba.z, g_ba.w));
-		off = FIXED >= 0 ? off + cb : opaque(off + cb);		// running sums as plain adds (opaque: not re-derived as e * cb with shifts)
-		offa = FIXED >= 0 ? offa + ab : opaque(offa + ab);
-	}
 	// With e0, e1 in 0..255 and w in 0..64 the reference's ((64-w)*e0 + w*e1 + 32) >> 6 (:182-193) equals the
 	// high byte of 256*e0 + 128 + 4*w*(e1 - e0) (range 128 .. 65408: fits a 16-bit lane, exact mod 2^16), so a
-	// texel is two v_pk_mad_u16 and one v_perm_b32 that gathers the four high bytes.
+	// texel is two v_pk_mad_u16 and one v_perm_b32 that gathers the four high bytes.  Per subset: its two endpoints
+	// expanded, then the row {base_rg, base_ba, 4*diff_rg, 4*diff_ba} parked in the lane's LDS column (nothing of a
+	// subset the wave does not have is computed, initialised or kept).
 #pragma unroll
 	for (int s = 0; s < 3; s++) {
 		if ((uint32_t)s >= wave_subsets) break;
+		uint32_t x_rg[2], x_ba[2];
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const int e = 2 * s + k;
+			// straight into the blend's 16-bit lanes: (R, G) and (B, A)
+			const uint32_t rg = (ubfe(wg, off, cb) << 16) | ubfe(wr, off, cb);
+			uint32_t ba = ubfe(wb, off, cb);
+			if (e < 4) ba |= ubfe(wa, offa, ab) << 16;		// modes with alpha have at most two subsets; ab = 0 reads 0
+			const uint32_t pm = (uint32_t)sbfe(pw, pidx[e], 1u);			// 0 / ~0: this endpoint's P-bit
+			x_rg[k] = or3(rg << g_c.y, pk_lshr_v(g_c.z, rg), pm & g_c.w);
+			x_ba[k] = or3(pk_lshl_v(g_ba.x, ba), pk_lshr_v(g_ba.y, ba), and_or(pm, g_ba.z, g_ba.w));
+			off = FIXED >= 0 ? off + cb : opaque(off + cb);		// running sums as plain adds (opaque: not re-derived as e * cb with shifts)
+			offa = FIXED >= 0 ? offa + ab : opaque(offa + ab);
+		}
 		uint4 row;
-		row.x = (x_rg[2 * s] << 8) | 0x00800080u;
-		row.y = (x_ba[2 * s] << 8) | 0x00800080u;
-		row.z = pk_lshl_v(0x00020002u, pk_sub_u16(x_rg[2 * s + 1], x_rg[2 * s]));	// 4*(e1-e0) per 16-bit lane (mod 2^16)
-		row.w = pk_lshl_v(0x00020002u, pk_sub_u16(x_ba[2 * s + 1], x_ba[2 * s]));
+		row.x = (x_rg[0] << 8) | 0x00800080u;
+		row.y = (x_ba[0] << 8) | 0x00800080u;
+		row.z = pk_lshl_v(0x00020002u, pk_sub_u16(x_rg[1], x_rg[0]));	// 4*(e1-e0) per 16-bit lane (mod 2^16)
+		row.w = pk_lshl_v(0x00020002u, pk_sub_u16(x_ba[1], x_ba[0]));
 		lane.put_subset(s, row);
 	}
 
@@ -402,8 +412,9 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	// Colour index stream: 64 stream bits from its start; texels 0-7 consume `half` of them, texels 8-15 start
 	// there.  Each window then gets the anchors' absent top bits inserted as zeros (w + (w & himask) doubles the
 	// part of w at and above the insertion point), after which texel k of a window sits at bit k*ib.
-	const uint4 g_ci = L.template group<F_ROW_C / 4>();		// row_c, pos_c, ibc, imask_c
-	const uint4 g_cw = L.template group<F_WMUL_C / 4>();		// wmul_c, wadd_c, sel_ba, half_a
+	Group g_ci = L.template group<F_ROW_C / 4>();		// row_c, pos_c, ibc, imask_c
+	Group g_cw = L.template group<F_WMUL_C / 4>();		// wmul_c, wadd_c, sel_ba, half_a
+	L.pin(g_ci, g_cw);
 	uint32_t c0, c1;
 	lane.field64(g_ci.x, g_ci.y, c0, c1);
 	const uint32_t route = pe.route;			// shifts use the low 5 bits of their amount
@@ -420,8 +431,9 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
 	if (any_two) {
 		// alpha stream (modes 4/5: one subset, the only anchor is texel 0)
-		const uint4 g_ai = L.template group<F_ROW_A2 / 4>();	// row_a2, pos_a2, iba, imask_a
-		const uint4 g_aw = L.template group<F_WMUL_A / 4>();	// wmul_a, wadd_a, himask0_a, -
+		Group g_ai = L.template group<F_ROW_A2 / 4>();	// row_a2, pos_a2, iba, imask_a
+		Group g_aw = L.template group<F_WMUL_A / 4>();	// wmul_a, wadd_a, himask0_a, -
+		L.pin(g_ai, g_aw);
 		uint32_t a0, a1;
 		lane.field64(g_ai.x, g_ai.y, a0, a1);
 		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, g_cw.w);
@@ -463,7 +475,6 @@ DH bool bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t mode_mask, uint3
 			}
 		}
 	}
-	return true;
 }
 
 // record of a block: its mode, +4 for mode 4 with the index-selection bit (block bit 7) set
@@ -501,28 +512,42 @@ template <bool UNIFORM> struct DecBPTCT {
 		return k < 3u ? in_rows : in_bits;
 	}
 #endif
+	// A block that fails -- reserved mode (decompress-bptc.c:229-237, 361) or, in the checked form, a mode outside
+	// mode_mask / the opaque flags (:363-369) -- is replaced by the mode-6 block whose other bits are all 0: endpoints,
+	// P-bits and indices 0, which decodes to sixteen zero pixels on the normal path.  A lane-divergent early return made
+	// every wave initialise sixteen result registers to zero first (and nearly every wave of a random stream holds a
+	// reserved block or none at all -- the moves ran either way).
+	static constexpr bool kZeroOnFailure = true;
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
-		if ((blk.x & 0xFFu) == 0u) return false;		// reserved (decompress-bptc.c:229-237, 361)
+		bool valid = (blk.x & 0xFFu) != 0u;
+		if (CHECKED) {
+			const uint32_t mode = (uint32_t)__builtin_ctz(blk.x | 0x100u);
+			valid = valid && (mode_mask & (1u << mode)) != 0u && !(mode >= 4u && (flags & kFlagOpaqueOnly)) &&
+				!(mode < 4u && (flags & kFlagNonOpaqueOnly));
+		}
+		const uint32_t keep = cond_to_mask(valid);
+		blk.x = bfi(keep, blk.x, 0x40u); blk.y &= keep; blk.z &= keep; blk.w &= keep;
 		const uint32_t r = bc7_record_index(blk.x);
 #if defined(__HIPCC__)
 		if (UNIFORM && !CHECKED) {
 			const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 			if (__builtin_amdgcn_ballot_w64(r != r0) == 0) {
 				switch (r0) {
-				case 0: return bc7_decode_with<0, false>(blk, r, mode_mask, flags, d);
-				case 1: return bc7_decode_with<1, false>(blk, r, mode_mask, flags, d);
-				case 2: return bc7_decode_with<2, false>(blk, r, mode_mask, flags, d);
-				case 3: return bc7_decode_with<3, false>(blk, r, mode_mask, flags, d);
-				case 4: return bc7_decode_with<4, false>(blk, r, mode_mask, flags, d);
-				case 5: return bc7_decode_with<5, false>(blk, r, mode_mask, flags, d);
-				case 6: return bc7_decode_with<6, false>(blk, r, mode_mask, flags, d);
-				case 7: return bc7_decode_with<7, false>(blk, r, mode_mask, flags, d);
-				default: return bc7_decode_with<8, false>(blk, r, mode_mask, flags, d);
+				case 0: bc7_decode_with<0>(blk, r, d); return valid;
+				case 1: bc7_decode_with<1>(blk, r, d); return valid;
+				case 2: bc7_decode_with<2>(blk, r, d); return valid;
+				case 3: bc7_decode_with<3>(blk, r, d); return valid;
+				case 4: bc7_decode_with<4>(blk, r, d); return valid;
+				case 5: bc7_decode_with<5>(blk, r, d); return valid;
+				case 6: bc7_decode_with<6>(blk, r, d); return valid;
+				case 7: bc7_decode_with<7>(blk, r, d); return valid;
+				default: bc7_decode_with<8>(blk, r, d); return valid;
 				}
 			}
 		}
 #endif
-		return bc7_decode_with<-1, CHECKED>(blk, r, mode_mask, flags, d);
+		bc7_decode_with<-1>(blk, r, d);
+		return valid;
 	}
 };
 using DecBPTC = DecBPTCT<Tune::kBc7Uniform>;

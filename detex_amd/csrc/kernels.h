@@ -200,6 +200,24 @@ template <int ROW, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
 	}
 }
 
+// one texel row of ROW dwords to a destination that is only dword-aligned
+template <int ROW> DH void store_row_dword_aligned(uint8_t *dst, const uint32_t *d) {
+	typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+	typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	typedef v2 v2a __attribute__((aligned(4)));
+	typedef v3 v3a __attribute__((aligned(4)));
+	typedef v4 v4a __attribute__((aligned(4)));
+	if constexpr (ROW == 1) __builtin_nontemporal_store(d[0], reinterpret_cast<uint32_t *>(dst));
+	else if constexpr (ROW == 2) __builtin_nontemporal_store(v2{ d[0], d[1] }, reinterpret_cast<v2a *>(dst));
+	else if constexpr (ROW == 3) __builtin_nontemporal_store(v3{ d[0], d[1], d[2] }, reinterpret_cast<v3a *>(dst));
+	else {
+#pragma unroll
+		for (int k = 0; k < ROW / 4; k++)
+			__builtin_nontemporal_store(v4{ d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }, reinterpret_cast<v4a *>(dst) + k);
+	}
+}
+
 // raise the "some block was invalid" word without an atomic RMW storm (see header comment)
 DH void raise_status(bool bad, uint32_t *status) {
 	if (status == nullptr) return;
@@ -357,6 +375,94 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	}
 }
 
+// ---- linear layout, any dword-aligned geometry: rows staged per workgroup, stores aligned to 64-byte sectors ---------------
+// A streaming store instruction whose 1 KiB run does not start on a 64-byte boundary leaves a partial sector at both ends, to
+// be completed by the neighbouring wave's store -- measured on this chip (tools/ubench/hbm_ref.hip, 256 MiB fill): runs at
+// offsets 4 .. 48 and 112 from a 64-byte boundary 4.4-4.5 TB/s, at offset 0 5.8, at offset 64 5.4.  decode_linear's runs
+// start on such boundaries only when every image row does (row bytes, pitch and base multiples of 64): a width like 8188 (row
+// = 32752 bytes), and every width that is not a multiple of four (clipped last block column, texture.c:116-120, 132-136; rows
+// 4 / 8 / 12 bytes off 16), lost 30-35 % (BC1 8188 x 8192 60.7 us, 8190 x 8190 63-64 us against 43 for 8192 x 8192).
+// Here a workgroup decodes up to 256 blocks of ONE block row, parks the four texel rows in LDS, and then writes each
+// texel row's byte range [x0, x1) of its image row in 16-byte vectors laid on the 64-byte grid of the ADDRESS SPACE (wave w
+// covers the w-th KiB from the sector boundary below the range), whatever the range's own alignment: only the first and the
+// last sector of a 4 KiB piece can be partial.  The image's right and bottom edges are clipped by the range, so clipped
+// textures need no separate edge pass.  Needs rows that are dword-aligned and a whole number of dwords long; anything else
+// (R8 / RG8 / RGB8 images of odd width) goes pixel by pixel through decode_linear_clipped.
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_staged(const void *__restrict__ blocks,
+		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t row_bytes, uint32_t height, uint64_t pitch,
+		uint32_t *__restrict__ status, uint32_t tiles_per_row) {
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
+	constexpr uint32_t PIECE = 4u * ROW;				// bytes of one block in one texel row
+	constexpr uint32_t SLACK = 8u, ROW_DWORDS = 256u * ROW + 2u * SLACK;	// a staged texel row: 32 bytes of slack in front and behind
+	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+	using Word = typename BlockWord<Dec::kBlockBytes>::type;
+	__shared__ __attribute__((aligned(16))) uint32_t stage[4][ROW_DWORDS];
+	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
+	const uint32_t by = blockIdx.x / tiles_per_row, tile = blockIdx.x - by * tiles_per_row;
+	const uint32_t bx = tile * 256u + threadIdx.x;
+	const bool live = bx < width_in_blocks;
+	Word blk = reinterpret_cast<const Word *>(blocks)[by * width_in_blocks + (live ? bx : width_in_blocks - 1u)];
+	pin_block(blk);
+	uint32_t o[4 * ROW];
+	bool ok = true;
+	if (live) {
+		ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			uint32_t *slot = &stage[r][SLACK + threadIdx.x * ROW];
+			if constexpr (ROW % 4 == 0) {
+#pragma unroll
+				for (int k = 0; k < ROW / 4; k++) reinterpret_cast<v4 *>(slot)[k] = v4{ o[r * ROW + 4 * k], o[r * ROW + 4 * k + 1], o[r * ROW + 4 * k + 2], o[r * ROW + 4 * k + 3] };
+			} else {
+#pragma unroll
+				for (int k = 0; k < ROW; k++) slot[k] = o[r * ROW + k];
+			}
+		}
+	}
+	__syncthreads();
+	if (live) raise_status(!ok, status);
+	const uint32_t x0 = tile * 256u * PIECE;				// the tile's byte range in its image rows, clipped at the image
+	const uint32_t grid_end = width_in_blocks * PIECE, x_end = row_bytes < grid_end ? row_bytes : grid_end;
+	const uint32_t x1 = x0 + 256u * PIECE < x_end ? x0 + 256u * PIECE : x_end;
+	if (x1 <= x0) return;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint32_t y = by * 4u + (uint32_t)r;
+		if (y >= height) break;
+		uint8_t *row = pixels + (uint64_t)y * pitch;
+		const uintptr_t g0 = reinterpret_cast<uintptr_t>(row) + x0, g1 = reinterpret_cast<uintptr_t>(row) + x1;
+		const uintptr_t base = g0 & ~(uintptr_t)63;			// the 64-byte grid of the address space
+		const uint32_t lead = (uint32_t)(g0 - base);			// 0 .. 60, a multiple of 4
+		const uint32_t n_chunks = (uint32_t)((g1 - base + 15u) >> 4);	// <= 256 * ROW / 4 + 4
+		const uint8_t *staged = reinterpret_cast<const uint8_t *>(&stage[r][SLACK]);
+		for (uint32_t c = threadIdx.x; c < n_chunks; c += 256u) {
+			const uintptr_t lo = base + 16u * c;
+			if (lo + 16u <= g0) continue;						// (up to three vectors of the first sector lie in front of the range)
+			const int32_t src = (int32_t)(16u * c) - (int32_t)lead;		// byte offset into the staged row; >= -12 here
+			// the two aligned 16-byte LDS vectors that contain the chunk (the slack keeps both inside the array)
+			const uint32_t shift = (uint32_t)src & 12u;
+			const v4 *q = reinterpret_cast<const v4 *>(staged + ((src - (int32_t)shift)));
+			const v4 a = q[0], b = q[1];
+			const uint32_t cat[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+			uint32_t d[4];
+			// (shift is the same for every chunk of the row: lead is)
+			if (shift == 0u) { d[0] = cat[0]; d[1] = cat[1]; d[2] = cat[2]; d[3] = cat[3]; }
+			else if (shift == 4u) { d[0] = cat[1]; d[1] = cat[2]; d[2] = cat[3]; d[3] = cat[4]; }
+			else if (shift == 8u) { d[0] = cat[2]; d[1] = cat[3]; d[2] = cat[4]; d[3] = cat[5]; }
+			else { d[0] = cat[3]; d[1] = cat[4]; d[2] = cat[5]; d[3] = cat[6]; }
+			if (lo >= g0 && lo + 16u <= g1) {
+				__builtin_nontemporal_store(v4{ d[0], d[1], d[2], d[3] }, reinterpret_cast<v4 *>(lo));
+			} else {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					if (lo + 4u * k >= g0 && lo + 4u * k + 4u <= g1) __builtin_nontemporal_store(d[k], reinterpret_cast<uint32_t *>(lo + 4u * k));
+			}
+		}
+	}
+}
+
 // ---- linear layout, fast path for narrow pixels: G horizontally adjacent blocks per lane ----------------------------
 // With one block per lane a texel row of R8 pixels is 4 bytes, so a wave's store instruction covers only a 256-byte run
 // (RGTC1 8192^2: 0.81 of the HBM rate even with the decode removed).  Here a lane decodes G consecutive blocks of one block
@@ -417,24 +523,6 @@ template <int ROW> DH void store_pixel(uint8_t *dst, const uint32_t *row, int x)
 	else { reinterpret_cast<uint32_t *>(dst)[0] = row[2 * x]; reinterpret_cast<uint32_t *>(dst)[1] = row[2 * x + 1]; }
 }
 
-// one texel row of ROW dwords to a destination that is only dword-aligned
-template <int ROW> DH void store_row_dword_aligned(uint8_t *dst, const uint32_t *d) {
-	typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-	typedef uint32_t v3 __attribute__((ext_vector_type(3)));
-	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-	typedef v2 v2a __attribute__((aligned(4)));
-	typedef v3 v3a __attribute__((aligned(4)));
-	typedef v4 v4a __attribute__((aligned(4)));
-	if constexpr (ROW == 1) __builtin_nontemporal_store(d[0], reinterpret_cast<uint32_t *>(dst));
-	else if constexpr (ROW == 2) __builtin_nontemporal_store(v2{ d[0], d[1] }, reinterpret_cast<v2a *>(dst));
-	else if constexpr (ROW == 3) __builtin_nontemporal_store(v3{ d[0], d[1], d[2] }, reinterpret_cast<v3a *>(dst));
-	else {
-#pragma unroll
-		for (int k = 0; k < ROW / 4; k++)
-			__builtin_nontemporal_store(v4{ d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }, reinterpret_cast<v4a *>(dst) + k);
-	}
-}
-
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
@@ -448,9 +536,8 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
 	uint32_t by, bx;
 	split_index(i, width_in_blocks, by, bx);
-	// blocks that lie completely inside the image write whole texel rows (vector stores that need only dword
-	// alignment: gfx950 global stores may be unaligned beyond that); only the blocks on the right / bottom edge, or
-	// every block when rows are not even dword-aligned, go pixel by pixel.  BC1 8190x8190: 102 -> 63 us (8192x8192: 43).
+	// blocks that lie completely inside the image write whole texel rows when rows are dword-aligned (vector stores
+	// that need no more than that); the others, or every block when rows are not even dword-aligned, go pixel by pixel
 	const bool rows_dword_aligned = ((reinterpret_cast<uintptr_t>(pixels) | pitch) & 3u) == 0;
 	if (rows_dword_aligned && bx * 4u + 4u <= width && by * 4u + 4u <= height) {
 		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);

@@ -108,7 +108,10 @@ template <int CLASS> DH uint32_t block_mode(const uint32_t *w) {	// w = the bloc
 // workgroup writes back / invalidates its XCD's L2 -- and 15-21 us with completion-ordered relaxed atomics, not provably
 // ordered.)
 constexpr int kHistogramLanes = 1024;
-template <int CLASS, int BLOCK_DWORDS>
+// PAIRED: two adjacent 32-bit bins per 64-bit atomic -- only where no bin can pass 2^32 (the zeroing entry: one call counts
+// fewer than 2^32 blocks); the accumulating entry adds 32-bit words, so a bin that overflows over many calls wraps instead
+// of carrying into its neighbour.
+template <int CLASS, int BLOCK_DWORDS, bool PAIRED>
 __global__ __launch_bounds__(kHistogramLanes) void mode_histogram(const uint32_t *__restrict__ blocks, uint32_t n_blocks,
 		uint32_t *__restrict__ hist) {
 	typedef typename BlockWord<4 * BLOCK_DWORDS>::type Word;
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(kHistogramLanes) void mode_histogram(const uint32_t
 	for (int step = 32; step >= 1; step >>= 1) sum += (uint32_t)__shfl_xor((int)sum, step, 64);
 	if (lane == 0) totals[m] = sum;
 	__syncthreads();
-	if (threadIdx.x < 8u) {		// (no carry between the two halves: a bin counts fewer than 2^32 blocks)
+	if (threadIdx.x < 8u) {
 		const uint32_t lo = totals[2u * threadIdx.x], hi = totals[2u * threadIdx.x + 1u];
-		if ((reinterpret_cast<uintptr_t>(hist) & 7u) == 0) {
+		if (PAIRED && (reinterpret_cast<uintptr_t>(hist) & 7u) == 0) {
 			if (lo | hi) atomicAdd(reinterpret_cast<unsigned long long *>(hist + 2u * threadIdx.x), (unsigned long long)lo | ((unsigned long long)hi << 32));
 		} else {
 			if (lo) atomicAdd(&hist[2u * threadIdx.x], lo);

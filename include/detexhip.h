@@ -79,7 +79,12 @@ DETEXHIP_API int detexhipDecompressTextureLinearDevice(uint32_t texture_format, 
  * it is timed separately and is never part of the decode time.  The call returns after everything completed:
  * 0 = ran (the reference's bool result is "no shard has invalid_blocks"), non-zero = usage / HIP error.
  * *decode_wall_ms: host clock from the first launch until the last kernel finished (uploads excluded);
- * *gather_wall_ms: the same clock until the last peer copy finished.  Serialised by an internal mutex.
+ * *gather_wall_ms: the same clock until the last peer copy finished.  Rows may be padded (pitch_bytes > width*pixel_size):
+ * a band is then gathered row by row and the bytes between the rows are left alone on both sides.
+ * Streams, events, status words and upload buffers are per calling thread and shard index, kept between calls
+ * (detexhipReleaseThreadResources() frees them): no lock is taken, concurrent callers do not share anything, and peer
+ * access is enabled once per process and device pair.  On failure everything this call launched has completed
+ * before it returns.
  */
 typedef struct {
 	int device;			/* in */
@@ -94,6 +99,19 @@ DETEXHIP_API int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_for
 	int width, int height, int width_in_blocks, int height_in_blocks, size_t pitch_bytes, uint32_t pixel_format,
 	detexhipShard *shards, int n_shards, int gather_device, void *d_gathered,
 	float *decode_wall_ms, float *gather_wall_ms);
+
+/*
+ * Host image in, host image out, over several devices: detexDecompressTextureLinear's contract (host pointers, clipping,
+ * invalid blocks zero-filled, only the pixels the block grid covers are written) with shard g of n_shards on devices[g] --
+ * each shard uploads its band of blocks, decodes it and downloads its band of pixels over ITS OWN PCIe link (one worker
+ * thread per shard; a device may be named more than once).  The single-device host tier is bounded by one link (~56 GB/s:
+ * 8192^2 RGBA8 pixels take 4.8 ms to download against 0.04 ms of kernel).  *any_invalid = 1 if a block was invalid (the
+ * reference's bool result is then false, and the same error text is left behind); returns non-zero on usage / HIP errors.
+ * *wall_ms: the whole call.
+ */
+DETEXHIP_API int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_format, const void *host_blocks,
+	int width, int height, int width_in_blocks, int height_in_blocks, void *host_pixels, size_t pitch_bytes,
+	uint32_t pixel_format, const int *devices, int n_shards, int *any_invalid, float *wall_ms);
 
 /* Device-resident counterpart of detexDecompressTextureTiled (texture.c:77-98): block i
  * occupies 16*pixel_size contiguous bytes of d_pixels (16-byte aligned); no clipping. */

@@ -1,0 +1,67 @@
+"""Seeded randomised parity cases shared by tests/test_gpu_parity.py::test_seeded_fuzz_slice (a fixed slice in `-m gpu`) and
+tools/gpu_fuzz.py (open-ended sweep on the GPU box).  One seed = every format once: a random geometry (power-of-two and
+non-power-of-two block widths, both sides of the several-blocks-per-lane condition, clipped sizes, a padded pitch now and
+then), a stream biased towards repeated blocks one time in three, decoded linear (native target and, one time in three, a
+random epilogue target), block-major and through the per-block API with a random mode mask -- each against the CPU oracle,
+bit for bit.  Test infrastructure only."""
+import numpy as np
+
+from detex_amd import formats as F
+import oracle_lib as ol
+
+GEOMETRIES = [(256, 64), (1024, 128), (72, 40), (100, 36), (4, 4), (260, 12), (1028, 8), (62, 30), (513, 17), (8000, 16), (1000, 52),
+              (2004, 24), (4093, 9), (36, 256), (12, 1024), (8192, 8), (1, 1), (3, 7), (4100, 4)]
+
+
+def run_seed(seed, oracle, binding, torch):
+    """returns the number of decode calls checked"""
+    rng = np.random.default_rng(seed)
+    cases = 0
+    for fmt in F.FORMATS:
+        W, H = GEOMETRIES[int(rng.integers(0, len(GEOMETRIES)))]
+        wb, hb = (W + 3) // 4, (H + 3) // 4
+        data = ol.stream_u(fmt, wb * hb, seed=int(rng.integers(1, 1 << 40)))
+        if rng.integers(0, 3) == 0:     # uniform waves, repeated rare-mode blocks
+            blk = data.reshape(-1, fmt.block_bytes)
+            src = blk[int(rng.integers(0, len(blk)))].copy()
+            blk[rng.integers(0, len(blk), max(1, len(blk) // int(rng.integers(2, 40))))] = src
+        dev = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        where = (fmt.name, W, H, seed)
+        # linear, native target, now and then into a padded pitch with a canary
+        px = fmt.pixel_bytes
+        pad = int(rng.integers(0, 4)) * (4 if px >= 4 else px) if rng.integers(0, 4) == 0 else 0
+        pitch = W * px + pad
+        ok_o, want = oracle.linear(fmt, data, W, H)
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        canvas = torch.full((H * pitch + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        binding.decompress_linear_device(fmt, dev, W, H, out=canvas, pitch=pitch, status=status)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy()
+        img = got[:H * pitch].reshape(H, pitch)
+        assert np.array_equal(img[:, :W * px].reshape(-1), np.asarray(want).reshape(-1)), ("linear",) + where + (pitch,)
+        assert (img[:, W * px:] == 0xA5).all() and (got[H * pitch:] == 0xA5).all(), ("linear wrote outside the image",) + where + (pitch,)
+        assert bool(status.item() == 0) == ok_o, ("status",) + where
+        cases += 1
+        # linear, an epilogue target
+        targets = [pf for pf in F.accepted_pixel_formats(fmt) if F.epilogue_kind(fmt, pf)]
+        if targets and rng.integers(0, 3) == 0:
+            pf = targets[int(rng.integers(0, len(targets)))]
+            _, want_pf = oracle.linear_to(fmt, data, W, H, pf)
+            got_pf = binding.decompress_linear_device(fmt, dev, W, H, pixel_format=pf)
+            torch.cuda.synchronize()
+            assert np.array_equal(got_pf.cpu().numpy().reshape(-1), np.asarray(want_pf).reshape(-1)), ("linear target 0x%04X" % pf,) + where
+            cases += 1
+        # block-major
+        _, want_t = oracle.tiled(fmt, data, wb, hb)
+        got_t = binding.decompress_tiled_device(fmt, dev, wb, hb)
+        torch.cuda.synchronize()
+        assert np.array_equal(got_t.cpu().numpy(), want_t), ("tiled",) + where
+        # per-block API with a random mode mask
+        mask = int(rng.integers(0, 1 << 14)) | (0 if rng.integers(0, 2) else 0xFFFFFFFF)
+        ok_b, want_b = oracle.blocks(fmt, data, mode_mask=mask)
+        got_b, got_ok = binding.decompress_blocks_device(fmt, dev, wb * hb, mode_mask=mask)
+        torch.cuda.synchronize()
+        assert np.array_equal(got_ok.cpu().numpy()[:wb * hb].astype(bool), ok_b), ("blocks ok", hex(mask)) + where
+        assert np.array_equal(got_b.cpu().numpy().reshape(-1)[:wb * hb * 16 * px], want_b.reshape(-1)), ("blocks", hex(mask)) + where
+        cases += 2
+    return cases

@@ -151,3 +151,88 @@ def test_multi_device_entry_matches_single_device(name, W, H, shards, torch_cuda
     rows = min(hb, 8)
     _, ref_rows = oracle.linear(fmt, data[:rows * wb * fmt.block_bytes], W, min(rows * 4, H))
     assert np.array_equal(want[:ref_rows.size], ref_rows)
+
+
+@pytest.mark.parametrize("name,W,H,shards,pad", [("BC1", 1024, 520, 3, 48), ("BPTC_FLOAT", 512, 256, 4, 64), ("RGTC1", 512, 36, 2, 7)])
+def test_multi_device_gather_with_padded_pitch(name, W, H, shards, pad, torch_cuda, oracle):
+    """pitch_bytes > width * pixel_size: a band is (rows - 1) * pitch + width * px bytes, so the gather must go row by row
+    and leave the bytes between the rows alone in the bands and in the gathered image alike (canaries)"""
+    from detex_amd import binding
+    fmt = F.BY_NAME[name]
+    px = fmt.pixel_bytes
+    unit = px if px < 4 else 4
+    pitch = W * px + (pad + unit - 1) // unit * unit
+    ndev = binding.load().detexhipGetDeviceCount()
+    devices = [g % ndev for g in range(shards)]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    data = ol.stream_u(fmt, wb * hb, seed=0x91C4 + fmt.index)
+    _, want = oracle.linear(fmt, data, W, H)
+    r = binding.decompress_linear_multi_device(fmt, W, H, devices, host_blocks=data, gather_device=0, pitch=pitch)
+    img = r["gathered"].cpu().numpy().reshape(H, pitch)
+    assert np.array_equal(img[:, :W * px].reshape(-1), want.reshape(-1))
+    assert (img[:, W * px:] == 0xA5).all(), "the gather wrote between the rows of the gathered image"
+    for band, s in zip(r["bands"], r["shards"]):
+        rows = max(0, min(s[1] * 4, H) - s[0] * 4)
+        b = band.cpu().numpy()[:rows * pitch].reshape(rows, pitch)
+        assert np.array_equal(b[:, :W * px].reshape(-1), want.reshape(H, W * px)[s[0] * 4:s[0] * 4 + rows].reshape(-1))
+        assert (b[:, W * px:] == 0xA5).all()
+
+
+@pytest.mark.parametrize("name,W,H,shards", [("BC1", 2048, 2048, 4), ("BPTC", 1022, 515, 3), ("BPTC_FLOAT", 1024, 512, 2), ("RGTC1", 516, 40, 8), ("BC1", 64, 64, 1)])
+def test_multi_device_host_entry(name, W, H, shards, torch_cuda, oracle, hiplib):
+    """detexhipDecompressTextureLinearMultiDeviceHost: host blocks in, host pixels out, one worker per shard (all on the
+    devices present: one on the test box) == the oracle == the single-device host tier, incl. clipped sizes, a padded pitch
+    with canaries, and the reference's bool result"""
+    from detex_amd import binding
+    fmt = F.BY_NAME[name]
+    px = fmt.pixel_bytes
+    ndev = binding.load().detexhipGetDeviceCount()
+    devices = [g % ndev for g in range(shards)]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    data = ol.stream_u(fmt, wb * hb, seed=0x405B + fmt.index)
+    ok_o, want = oracle.linear(fmt, data, W, H)
+    ok, got, wall = binding.decompress_linear_multi_device_host(fmt, data, W, H, devices)
+    assert ok == ok_o and np.array_equal(got, want.reshape(-1)) and wall > 0
+    ok_h, got_h = hiplib.linear(fmt, data, W, H)
+    assert ok_h == ok and np.array_equal(got_h.reshape(-1), got)
+    pitch = W * px + 4 * (px if px < 4 else 4)
+    canvas = np.full(H * pitch, 0xA5, np.uint8)
+    ok2, _, _ = binding.decompress_linear_multi_device_host(fmt, data, W, H, devices, out=canvas, pitch=pitch)
+    img = canvas.reshape(H, pitch)
+    assert ok2 == ok_o and np.array_equal(img[:, :W * px].reshape(-1), want.reshape(-1)) and (img[:, W * px:] == 0xA5).all()
+    if not ok_o:
+        assert b"returned error" in binding.load().detexGetErrorMessage()
+
+
+def test_multi_device_entries_from_concurrent_threads(torch_cuda, oracle):
+    """the multi-device entries keep their streams / buffers per calling thread and take no lock: several threads calling
+    at once get their own results"""
+    import threading
+    from detex_amd import binding
+    binding.load()
+    fmt = F.BY_NAME["BC3"]
+    errors = []
+
+    def worker(t):
+        try:
+            W, H = 512 + 64 * t, 256
+            data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0x7700 + t)
+            _, want = oracle.linear(fmt, data, W, H)
+            for _ in range(4):
+                r = binding.decompress_linear_multi_device(fmt, W, H, [0, 0, 0], host_blocks=data, gather_device=0)
+                if not np.array_equal(r["gathered"].cpu().numpy(), want.reshape(-1)):
+                    errors.append(("device entry", t))
+                ok, got, _ = binding.decompress_linear_multi_device_host(fmt, data, W, H, [0, 0])
+                if not np.array_equal(got, want.reshape(-1)):
+                    errors.append(("host entry", t))
+            lib = binding.load()
+            lib.detexhipReleaseThreadResources.restype = None
+            lib.detexhipReleaseThreadResources()
+        except Exception as e:  # noqa
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

@@ -356,6 +356,72 @@ def test_full_size_digest(name, torch_cuda, golden_json):
         torch.cuda.empty_cache()
 
 
+def test_seeded_fuzz_slice(torch_cuda, oracle):
+    """A fixed slice of the randomised sweep of tools/gpu_fuzz.py (tests/fuzz.py): 300 seeds x 19 formats, ~20 k decode calls
+    -- non-power-of-two block widths, all pixel sizes, padded pitches, epilogue targets, block-major, random mode masks."""
+    from detex_amd import binding
+    import fuzz
+    binding.load()
+    cases = sum(fuzz.run_seed(seed, oracle, binding, torch_cuda) for seed in range(1000, 1300))
+    assert cases >= 300 * 19 * 3
+
+
+@pytest.mark.parametrize("name", ["BPTC_FLOAT", "BPTC_SIGNED_FLOAT", "BC3", "BPTC", "RGTC2", "RGTC1", "SIGNED_RGTC1", "EAC_RG11"])
+def test_wide_non_power_of_two_band_vs_oracle(name, torch_cuda, oracle):
+    """8000 pixels wide (2000 blocks per row: the division branch of split_index, waves and 64-bit-pixel transposes that
+    straddle block rows, several-blocks-per-lane rows) on a band of 64 block rows, against the ORACLE (test_properties_full_size
+    compares such widths with themselves only)."""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    W, H = 8000, 256
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0x8000 + fmt.index)
+    ok_o, want = oracle.linear(fmt, data, W, H)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+    torch.cuda.synchronize()
+    g = got.cpu().numpy().reshape(-1)
+    assert np.array_equal(g, want.reshape(-1)), (name, _first_diff(g, want.reshape(-1), fmt.pixel_bytes))
+    assert bool(status.item() == 0) == ok_o
+    _, want_t = oracle.tiled(fmt, data, W // 4, H // 4)
+    got_t = binding.decompress_tiled_device(fmt, _dev(torch, data), W // 4, H // 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_t.cpu().numpy(), want_t), name
+
+
+def test_clipped_large_digests(torch_cuda, golden_json, oracle):
+    """Large textures whose width / height are not multiples of four (texture.c:116-120, 132-136) against digests of the
+    compiled reference's output: the interior goes through the throughput kernel (rows 16-byte aligned, or only dword-aligned
+    when an odd width puts every other row 4 / 8 / 12 bytes off), the last block column / row through the per-pixel kernel,
+    and widths whose rows are not even dword-aligned (R8 4093 wide, RGB8 4094 wide) through that kernel as a whole.  A canary
+    behind the image must survive; the first 64 rows are also compared with the oracle so a failure names a pixel."""
+    from detex_amd import binding
+    torch = torch_cuda
+    dg = golden_json("digests_8192.json")["clipped"]
+    for key, g in dg.items():
+        parts = key.split("/")
+        fmt = F.BY_NAME[parts[0]]
+        W, H = (int(v) for v in parts[1].split("x"))
+        pf = int(parts[2][2:], 16) if len(parts) > 2 else F.native_pixel_format(fmt)
+        px = 1 + ((pf & 0xF00) >> 8)
+        wb, hb = (W + 3) // 4, (H + 3) // 4
+        data = ol.stream_u(fmt, wb * hb)
+        assert sha(data) == g["in_sha256"]
+        canvas = torch.full((W * H * px + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        binding.decompress_linear_device(fmt, _dev(torch, data), W, H, out=canvas, pixel_format=pf, status=status)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy()
+        assert (got[W * H * px:] == 0xA5).all(), (key, "wrote past the image")
+        rows = min(64, H)
+        _, want = oracle.linear_to(fmt, data[:((rows + 3) // 4) * wb * fmt.block_bytes], W, rows, pf)
+        assert np.array_equal(got[:rows * W * px], want), (key, _first_diff(got[:rows * W * px], want, px))
+        assert bool(status.item() == 0) == g["ok"], key
+        assert g["bytes"] == W * H * px and sha(got[:W * H * px]) == g["sha256"], key
+        del canvas
+        torch.cuda.empty_cache()
+
+
 # ---- size-independent properties at full size -----------------------------------------------------
 @pytest.mark.parametrize("name,W,H", [("BC1", 4096, 4096), ("BPTC", 4096, 4096), ("BPTC_FLOAT", 4096, 4096), ("BPTC_SIGNED_FLOAT", 4096, 2048),
                                       ("RGTC1", 4096, 4096), ("EAC_R11", 4096, 2048), ("BPTC_FLOAT", 8000, 2000), ("BC3", 8000, 2000),

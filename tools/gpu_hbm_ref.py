@@ -30,6 +30,14 @@ for mib in (256, 1024):
     for nt in (True, False):
         gbps, us = hbmref.copy_GBps(mib << 20, nt, 30)
         emit({"op": "copy", "MiB": mib, "nontemporal": nt, "us": round(us, 1), "TBps_read_plus_written": round(gbps / 1e3, 3)})
+# the fill in the decode kernels' image layout, and through stores that are only dword-aligned
+for (wbytes, h) in ((32768, 8192), (65536, 8192), (65536, 16384)):
+    for pat in (0, 2):
+        gbps, us = hbmref.fill_image_GBps(wbytes, h, pat, 30)
+        emit({"op": "fill_image", "width_bytes": wbytes, "height": h, "MiB": wbytes * h >> 20, "pattern": pat, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
+for off in (0, 4, 8, 12, 16, 32, 48, 64, 112):
+    gbps, us = hbmref.fill_unaligned_GBps(256 << 20, off, 30)
+    emit({"op": "fill_dword_aligned_stores", "MiB": 256, "offset": off, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
 # torch's own fill / zero / copy for comparison with round 1's table
 for mib in (256, 1024):
     n = (mib << 20) // 4

@@ -13,7 +13,8 @@ What it writes is data only -- inputs and the reference's outputs:
   tests/golden/digests_8192.json    sha256 (+ FNV-1a-64) of the reference output on the 8192x8192 streams U (all formats),
                                     M (BPTC, BPTC_FLOAT) and C (every format with a fixture), on converted targets, and on
                                     whole 32768-wide bands of the sharded configs
-usage: python tools/make_goldens.py [fixtures] [vectors] [digests] [digests_c] [digests_pf] [bands]   (default: all)
+                                    ("clipped": large textures whose width / height are not multiples of four)
+usage: python tools/make_goldens.py [fixtures] [vectors] [digests] [digests_c] [digests_pf] [bands] [clipped]   (default: all)
 """
 import ctypes, hashlib, json, os, shutil, sys, time
 import numpy as np
@@ -50,7 +51,7 @@ def ref_linear_mt(ref, f, data, W, H, pf=None, threads=None):
 
 
 def main():
-    sections = set(sys.argv[1:]) or {"fixtures", "vectors", "digests", "digests_c", "digests_pf", "bands"}
+    sections = set(sys.argv[1:]) or {"fixtures", "vectors", "digests", "digests_c", "digests_pf", "bands", "clipped"}
     os.makedirs(G, exist_ok=True)
     ref = ol.load_ref(); orc = ol.Oracle()
     orc.lib.orc_fnv1a64.restype = ctypes.c_uint64
@@ -104,7 +105,46 @@ def main():
             t = time.time(); ok, out = ref_linear_mt(ref, f, data, bw, bh); dt = time.time() - t
             dg["bands"]["%s/%dx%d" % (name, bw, bh)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
             print(name, bw, bh, ok, "%.1fs" % dt, flush=True)
+    if "clipped" in sections:
+        # large textures with clipped last block column / row (texture.c:116-120, 132-136): interior through the throughput
+        # kernel (aligned and dword-aligned rows), edge strips pixel by pixel, and widths whose rows are not even dword-aligned
+        dg["clipped"] = {}
+        for name, w, h, pf in CLIPPED_CASES:
+            f = F.BY_NAME[name]
+            wb, hb = (w + 3) // 4, (h + 3) // 4
+            data = ol.stream_u(f, wb * hb)
+            ok, out = ref_linear_clipped_mt(ref, f, data, w, h, pf)
+            key = "%s/%dx%d" % (name, w, h) + ("/pf%04X" % pf if pf else "")
+            dg["clipped"][key] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
+            print("clipped", key, ok, flush=True)
     json.dump(dg, open(dpath, "w"), indent=1, sort_keys=True)
+
+
+CLIPPED_CASES = [("BC1", 8190, 8190, None), ("BPTC", 4093, 4091, None), ("BPTC_FLOAT", 4093, 2047, None), ("RGTC1", 4093, 2047, None),
+                 ("RGTC2", 4094, 2046, None), ("EAC_R11", 4094, 2045, None), ("BC3", 4094, 2046, F.PIXEL_FORMAT_RGB8),
+                 ("ETC2_EAC", 8190, 4096, None), ("BC1", 8192, 8190, None)]
+
+
+def ref_linear_clipped_mt(ref, f, data, W, H, pf=None, threads=None):
+    """as ref_linear_mt for a texture whose width / height need not be multiples of four"""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or min(16, os.cpu_count() or 1)
+    pf = (f.texture_format & 0xFFFF) if pf is None else pf
+    px = 1 + ((pf & 0xF00) >> 8)
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    out = np.empty(W * H * px, np.uint8)
+    data = np.ascontiguousarray(data)
+
+    def band(g):
+        r0, r1 = g * hb // threads, (g + 1) * hb // threads
+        if r1 <= r0:
+            return True
+        rows = min(r1 * 4, H) - r0 * 4
+        tex = ol.DetexTexture(f.texture_format, ol._ptr(data[r0 * wb * f.block_bytes:]), W, rows, wb, r1 - r0)
+        return bool(ref.lib.detexDecompressTextureLinear(ctypes.byref(tex), ol._ptr(out[r0 * 4 * W * px:]), pf))
+    with ThreadPoolExecutor(threads) as pool:
+        oks = list(pool.map(band, range(threads)))
+    return all(oks), out
 
 
 def make_fixtures(ref):

@@ -42,6 +42,27 @@ template <int PATTERN, bool NT> __global__ __launch_bounds__(256) void fill_kern
 	}
 }
 
+// the same fill through stores that are only dword-aligned (what an odd texture width does to every other pixel row)
+typedef v4 v4_dword_aligned __attribute__((aligned(4)));
+__global__ __launch_bounds__(256) void fill_unaligned_kernel(uint8_t *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint64_t i = base + (uint64_t)r * 256u + threadIdx.x;
+		if (i < n_vectors) __builtin_nontemporal_store(make_vector<2>((uint32_t)i, seed), reinterpret_cast<v4_dword_aligned *>(dst + 16u * i));
+	}
+}
+
+// the fill laid out like a decoded image: workgroup b writes four rows of `pitch_vectors`-wide image rows, 256 vectors (4 KiB)
+// of each -- the texel rows of one 256-block tile -- instead of 16 consecutive KiB
+template <int PATTERN> __global__ __launch_bounds__(256) void fill_image_kernel(v4 *__restrict__ dst, uint32_t pitch_vectors, uint32_t tiles_per_row, uint32_t seed) {
+	const uint32_t ty = blockIdx.x / tiles_per_row, tx = blockIdx.x - ty * tiles_per_row;
+	v4 *p = dst + (uint64_t)(4u * ty) * pitch_vectors + (uint64_t)tx * 256u + threadIdx.x;
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+		__builtin_nontemporal_store(make_vector<PATTERN>(blockIdx.x * 1024u + r * 256u + threadIdx.x, seed), p + (uint64_t)r * pitch_vectors);
+}
+
 template <bool NT> __global__ __launch_bounds__(256) void copy_kernel(v4 *__restrict__ dst, const v4 *__restrict__ src, uint64_t n_vectors) {
 	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
 	v4 v[4];
@@ -77,5 +98,24 @@ extern "C" __attribute__((visibility("default"))) int hbmref_copy(void *dst, con
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (nontemporal) hipLaunchKernelGGL((copy_kernel<true>), grid, block, 0, s, static_cast<v4 *>(dst), static_cast<const v4 *>(src), n);
 	else hipLaunchKernelGGL((copy_kernel<false>), grid, block, 0, s, static_cast<v4 *>(dst), static_cast<const v4 *>(src), n);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// dst may be any dword-aligned address
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_unaligned(void *dst, size_t bytes, uint32_t seed, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || (reinterpret_cast<uintptr_t>(dst) & 3u)) return 1;
+	hipLaunchKernelGGL(fill_unaligned_kernel, dim3((unsigned)((n + 1023u) / 1024u)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t *>(dst), n, seed);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// width_bytes x height image (width a multiple of 4096 bytes, height of 4 rows), pattern 0 or 2
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_image(void *dst, size_t width_bytes, size_t height, int pattern, uint32_t seed, void *stream) {
+	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const uint32_t tiles_per_row = (uint32_t)(width_bytes / 4096u), pitch_vectors = (uint32_t)(width_bytes / 16u);
+	const dim3 grid((unsigned)(tiles_per_row * (height / 4u))), block(256);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (pattern == 0) hipLaunchKernelGGL((fill_image_kernel<0>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
+	else hipLaunchKernelGGL((fill_image_kernel<2>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
