@@ -9,18 +9,31 @@ prints ONE JSON line on rank 0.
             HBM into a device-resident linear image.
   N == 1    workload = BASELINE.json configs[1]: BC1 -> RGBA8, 8192 x 8192, synthetic stream U
             (splitmix64, tests/oracle_lib.py).  Extra keys: `per_format` (the six headline formats
-            of configs[1..4] at 8192^2, streams U/M/C, each timed at steady state),
-            `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`, `cpu_baseline`.
+            of configs[1..4] at 8192^2, streams U/M/C, plus the weakest kernels -- signed BC6H,
+            block-major BC7, RGTC1 -- each timed at steady state), `beyond_mall`,
+            `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`,
+            `host_tier_small` (per-call latency of small textures / one block through the host API,
+            beside the reference on one host thread), `cpu_baseline`.
   N > 1     BASELINE north_star: ONE 32768 x 32768 BC1 image sharded by block rows over the ranks
             (contiguous input and output ranges per rank, NO data-path collective)
             -> "scaling": "strong", value = 32768^2 * K / max-over-ranks(wall time of K steps).
             RCCL is used for the timing barrier / max-reduction only.  Extra keys: `weak` (one
-            8192^2 image per rank), `gather` (the optional whole-image all-gather over xGMI through
-            detex_amd.sharding.gather_image, timed separately, never part of `value`),
-            `rccl_ranks` (ranks that answered an all_reduce).  --weak restores the round-1 line.
+            8192^2 image per rank), `gather` (the optional whole-image gather over xGMI, timed
+            separately and never part of `value`: `to_root` = grouped point-to-point sends into one
+            rank's image, `to_all` = one all_gather_into_tensor), `bc6h_32768` (BASELINE configs[4]:
+            BPTC_FLOAT -> FLOAT_RGBX16, 32768^2 over the ranks, decode-only + its gathers, rank 0's
+            whole band checked against the reference's digest when N = 8), `rccl_ranks` (ranks that
+            answered an all_reduce).  --weak restores the round-1 line.
   roofline  algorithmic bytes per launch (blocks * (block_bytes + 16*pixel_bytes)) / average
             launch duration from HIP events recorded on the launch stream around the timed
-            region; peak = 8 TB/s (MI355X_MICROARCH.md).
+            region; peak = 8 TB/s (MI355X_MICROARCH.md).  Measured in the same process beside it
+            (tools/ubench/hbm_ref.hip): ref_fill_GBps = a write-only fill of 1 GiB with the decode
+            kernels' store shape, ref_fill_same_shape_GBps = that fill over the workload's own
+            output image, ref_copy_GBps = a 1 GiB 16-byte-vector copy (read + written);
+            frac_of_measured_fill = the kernel's WRITE rate / ref_fill_same_shape,
+            frac_of_measured_copy = its read + write rate / ref_copy.  `beyond_mall`: the same
+            format at 16384^2 (1 GiB of pixels: the 8192^2 output, 256 MiB, is exactly the size of
+            the Infinity Cache).
   cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or our C restatement
             (kind "port") decoding the same stream on the host cores; rank 0, N == 1 only.
 """
@@ -39,6 +52,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0
 HEADLINE_FORMATS = ["BC1", "BC3", "BPTC", "ETC2", "ETC2_EAC", "BPTC_FLOAT"]
+# the kernels furthest below the roofline / with the shortest launches, reported beside the headline formats: (format, stream, layout)
+WEAK_KERNELS = [("BPTC_SIGNED_FLOAT", "U", "linear"), ("BPTC", "U", "tiled"), ("RGTC1", "U", "linear")]
 
 
 def log(*a):
@@ -252,29 +267,53 @@ def main():
         except Exception:  # noqa
             return None
 
+    def hbm_reference(job):
+        """write-only fill and copy rates of this box, this process (reference points for the roofline fraction)"""
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hbmref
+            ref = {}
+            g, us = hbmref.fill_image_GBps(65536, 16384, 2, 20)
+            ref["ref_fill_GBps"] = round(g, 1)
+            row_bytes = job.W * job.tpx
+            if job.layout == "linear" and row_bytes % 4096 == 0 and job.H % 4 == 0:
+                g2, _ = hbmref.fill_image_GBps(row_bytes, job.H, 2, 40)
+                ref["ref_fill_same_shape_GBps"] = round(g2, 1)
+            c, _ = hbmref.copy_GBps(1 << 30, True, 10)
+            ref["ref_copy_GBps"] = round(c, 1)
+            ref["ref_note"] = ("same process: 1 GiB image-layout fill (four non-temporal 16-byte stores per lane, 1 KiB runs), the same fill "
+                               "over this workload's output image, 1 GiB copy (bytes read + written)")
+            torch.cuda.empty_cache()
+            return ref
+        except Exception as e:  # noqa
+            log("hbm reference legs failed:", e)
+            return {}
+
     fmt = F.BY_NAME[args.format]
-    strong = args.strong_image if args.strong_image is not None else (0 if (world == 1 or args.weak) else 32768)
+    # (plumbing runs over gloo move CUDA tensors through the host at ~0.03 GB/s point-to-point: they get small images)
+    big = 32768 if backend == "nccl" else 2048
+    strong = args.strong_image if args.strong_image is not None else (0 if (world == 1 or args.weak) else big)
     W = H = args.size
     if args.band_height:
         H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
     if strong:
         shard = sharding.shard_of(rank, world, fmt, strong, strong)
         W, H = strong, (shard.row1 - shard.row0) * 4
-    if strong and args.stream != "C":
-        # the image's stream is defined over the whole image; a rank materialises only its band of it
-        wb = W // 4
-        words_per_row = wb * fmt.block_bytes // 8
-        seed = stream_seed(fmt, 0)
-        # splitmix64 is counter-based: word k depends on k only, so the band is the slice [row0*wpr, row1*wpr)
+    def band_stream(f, image_side, sh, kind="U"):
+        """this rank's band of the image's block stream: splitmix64 is counter-based (word k depends on k only), so the
+        band is the slice [row0 * words_per_row, row1 * words_per_row) and a rank materialises nothing else"""
+        words_per_row = (image_side // 4) * f.block_bytes // 8
         with np.errstate(over="ignore"):
-            k = np.arange(shard.row0 * words_per_row + 1, shard.row1 * words_per_row + 1, dtype=np.uint64)
-            z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * k
+            k = np.arange(sh.row0 * words_per_row + 1, sh.row1 * words_per_row + 1, dtype=np.uint64)
+            z = np.uint64(stream_seed(f, 0)) + np.uint64(0x9E3779B97F4A7C15) * k
             z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
             z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
             z = z ^ (z >> np.uint64(31))
-        data = z.view(np.uint8)
-        if args.stream == "M":
-            data = streams.stream_m(fmt, data)
+        d = z.view(np.uint8)
+        return streams.stream_m(f, d) if kind == "M" else d
+
+    if strong and args.stream != "C":
+        data = band_stream(fmt, strong, shard, args.stream)
     else:
         data = make_input(fmt, W // 4, H // 4, args.stream, 0 if strong else rank)
         if data is None:
@@ -295,29 +334,78 @@ def main():
 
     extras = {}
     if world > 1 and not args.no_extras:
-        # (a) the optional whole-image gather, through the library function (one all_gather_into_tensor straight into the image)
-        if strong:
+        def time_gathers(f, side, sh, band, reps=2):
+            """the optional whole-image gather, timed separately from the decode (never part of `value`): to ONE rank with grouped
+            point-to-point sends (the root's links to all peers busy at once, nothing lands elsewhere) and to EVERY
+            rank with one all_gather_into_tensor straight into the final image"""
+            out = {}
             try:
-                ok, image = sharding.gather_image(dist, torch, fmt, strong, strong, shard, job.d_out, True)
-                barrier()
-                t0 = time.perf_counter()
-                reps = 3
+                ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True)
+                barrier(); t0 = time.perf_counter()
                 for _ in range(reps):
-                    ok, image = sharding.gather_image(dist, torch, fmt, strong, strong, shard, job.d_out, True, image=image)
-                barrier()
-                g_ms = (time.perf_counter() - t0) / reps * 1e3
-                mine = image[shard.out_offset:shard.out_offset + shard.out_bytes]
-                same = bool(torch.equal(mine, job.d_out[:shard.out_bytes]))
-                other = sharding.shard_of((rank + 1) % world, world, fmt, strong, strong)
-                probe = image[other.out_offset:other.out_offset + 4096].cpu().numpy()
-                extras["gather"] = {"op": "sharding.gather_image (all_gather_into_tensor into the final image)", "ms": round(g_ms, 3),
-                                    "bytes_per_rank": int(shard.out_bytes), "image_bytes": int(image.numel()),
-                                    "GBps_received_per_rank": round((image.numel() - shard.out_bytes) / (g_ms * 1e-3) / 1e9, 1),
-                                    "own_band_intact": same, "peer_band_nonzero": bool(probe.any()),
-                                    "decode_plus_gather_ms": round(wall / args.steps * 1e3 + g_ms, 3)}
+                    ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True, image=image)
+                barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
+                row = {"op": "sharding.gather_image_to_root (grouped isend / irecv into the root's image)", "ms": round(ms, 3), "bytes_per_rank": int(sh.out_bytes)}
+                if rank == 0:
+                    other = sharding.shard_of(world - 1, world, f, side, side)
+                    row["GBps_into_root"] = round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1)
+                    row["own_band_intact"] = bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes]))
+                    row["peer_band_nonzero"] = bool(image[other.out_offset:other.out_offset + 4096].any().item())
+                out["to_root"] = row
                 del image
             except Exception as e:  # noqa
-                extras["gather"] = {"error": repr(e)}
+                out["to_root"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True)
+                barrier(); t0 = time.perf_counter()
+                for _ in range(reps):
+                    ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True, image=image)
+                barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
+                other = sharding.shard_of((rank + 1) % world, world, f, side, side)
+                out["to_all"] = {"op": "sharding.gather_image (all_gather_into_tensor into the final image)", "ms": round(ms, 3), "image_bytes": int(image.numel()),
+                                 "GBps_received_per_rank": round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1),
+                                 "own_band_intact": bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes])),
+                                 "peer_band_nonzero": bool(image[other.out_offset:other.out_offset + 4096].any().item())}
+                del image
+            except Exception as e:  # noqa
+                out["to_all"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            return out
+
+        # (a) the optional whole-image gather of the headline image
+        if strong:
+            extras["gather"] = time_gathers(fmt, strong, shard, job.d_out)
+            extras["gather"]["decode_ms_per_step"] = round(wall / args.steps * 1e3, 4)
+        # (a') BASELINE configs[4]: BC6H -> FLOAT_RGBX16 ("FP16 RGBA"), 32768^2 sharded over the ranks, decode-only and gather separately
+        if strong and fmt.name != "BPTC_FLOAT":
+            try:
+                f6 = F.BY_NAME["BPTC_FLOAT"]
+                sh6 = sharding.shard_of(rank, world, f6, big, big)
+                d6 = band_stream(f6, big, sh6)
+                j6 = Job(f6, big, (sh6.row1 - sh6.row0) * 4, d6)
+                w6, ms6 = timed(j6, args.steps, max(args.warmup, 10))
+                v6 = j6.verify(16)
+                digest = None
+                if world == 8 and rank == 0 and big == 32768:            # the first band of the image is the golden band of tests/golden/digests_8192.json
+                    import hashlib
+                    try:
+                        want = json.load(open(os.path.join(ROOT, "tests", "golden", "digests_8192.json")))["bands"]["BPTC_FLOAT/32768x4096"]["sha256"]
+                        digest = hashlib.sha256(j6.d_out.cpu().numpy().tobytes()).hexdigest() == want
+                    except Exception as e:  # noqa
+                        digest = repr(e)
+                v = torch.tensor([v6], dtype=torch.int32, device=coll_dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                row = {"workload": "BPTC_FLOAT->FLOAT_RGBX16, ONE %dx%d image (stream U) sharded by block rows over %d GPU(s): %d rows per GPU, no data-path collective"
+                                   % (big, big, world, (sh6.row1 - sh6.row0) * 4),
+                       "value_gpixel_s": round(big * big * args.steps / w6 / 1e9, 3), "ms_per_step": round(w6 / args.steps * 1e3, 5), "launch_us": round(ms6 * 1e3, 3),
+                       "frac": round(j6.alg_bytes / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "verified_bit_exact_rows_min_over_ranks": int(v.item()),
+                       "rank0_whole_band_digest_matches_reference": digest}
+                row["gather"] = time_gathers(f6, big, sh6, j6.d_out, reps=1)
+                extras["bc6h_32768"] = row
+                del j6
+            except Exception as e:  # noqa
+                extras["bc6h_32768"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         # (b) weak scaling: one 8192^2 image per rank
         if strong:
@@ -356,6 +444,15 @@ def main():
     if verified_rows == 0:
         log("bench.py: OUTPUT MISMATCH against the oracle")
         result["value"] = 0.0
+    if world == 1 and not args.no_extras:
+        ref = hbm_reference(job)
+        result["roofline"].update(ref)
+        write_gbps = job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9
+        result["roofline"]["write_GBps"] = round(write_gbps, 1)
+        if ref.get("ref_fill_same_shape_GBps") or ref.get("ref_fill_GBps"):
+            result["roofline"]["frac_of_measured_fill"] = round(write_gbps / (ref.get("ref_fill_same_shape_GBps") or ref["ref_fill_GBps"]), 4)
+        if ref.get("ref_copy_GBps"):
+            result["roofline"]["frac_of_measured_copy"] = round(achieved / ref["ref_copy_GBps"], 4)
     t = pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
     if t:
         result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
@@ -400,9 +497,31 @@ def main():
                     row["traffic"] = tr["hbm_bytes_per_launch"]
                 table["%s/%s" % (name, kind)] = row
                 del j
+        for name, kind, layout in WEAK_KERNELS:
+            f = F.BY_NAME[name]
+            j = Job(f, 8192, 8192, make_input(f, 2048, 2048, kind), layout)
+            us, launches = steady_state_us(j)
+            row = roofline_of(j, us)
+            row["launches_before_reading"] = launches
+            table["%s/%s" % (name, kind) + ("/tiled" if layout == "tiled" else "")] = row
+            del j
         torch.cuda.empty_cache()
         result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran)",
                                 "seconds": round(time.perf_counter() - t_start, 2), "formats": table}
+        # the headline format beyond the Infinity Cache: 16384^2 = 1 GiB of pixels
+        try:
+            f = F.BY_NAME[args.format]
+            j = Job(f, 16384, 16384, make_input(f, 4096, 4096, "U"))
+            us, launches = steady_state_us(j, window=25, max_windows=8, min_launches=100)
+            row = roofline_of(j, us)
+            row["workload"] = "%s 16384x16384 stream U" % f.name
+            if result["roofline"].get("ref_fill_GBps"):
+                row["frac_of_measured_fill"] = round(j.blocks * 16 * j.tpx / (us * 1e-6) / 1e9 / result["roofline"]["ref_fill_GBps"], 4)
+            result["beyond_mall"] = row
+            del j
+        except Exception as e:  # noqa
+            log("beyond_mall failed:", e)
+        torch.cuda.empty_cache()
         # this GPU alone on the N > 1 workload (so the driver's scaling curve has a like-for-like N = 1 point)
         try:
             f = F.BY_NAME["BC1"]
@@ -416,6 +535,38 @@ def main():
         except Exception as e:  # noqa
             log("strong_image_32768 failed:", e)
         torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_extras:
+        # small inputs through the reference's own entry points (host pointers): where the PCIe-attached decoder loses to one
+        # host thread.  Per call, including the ctypes call overhead on both sides (~2 us).
+        try:
+            def per_call_us(fn, budget_s=0.2, min_calls=20):
+                fn(); fn()
+                t0 = time.perf_counter(); n = 0
+                while n < min_calls or time.perf_counter() - t0 < budget_s:
+                    fn(); n += 1
+                return (time.perf_counter() - t0) / n * 1e6
+            api = ol.DetexAPI(binding.LIB_PATH)
+            ref_api = ol.load_ref() if ol.have_ref() else None
+            small = {"note": "us per call: detexDecompressTextureLinear(BC1 -> RGBA8, host pointers) and the one-block leaf function; "
+                             "textures up to 1.25 MiB of blocks + pixels are exchanged through pinned host memory (one launch + one "
+                             "synchronisation), larger ones staged through device buffers"}
+            f1 = F.BY_NAME["BC1"]
+            blk = ol.stream_u(f1, 1, seed=5)
+            o16 = np.zeros(64, np.uint8)
+            for label, a in (("gpu", api), ("reference_1thread", ref_api)):
+                if a is None:
+                    continue
+                fn = a.block_fn(f1)
+                row = {"one_block_us": round(per_call_us(lambda: fn(ol._ptr(blk), 0xFFFFFFFF, 0, ol._ptr(o16))), 2)}
+                for side in (64, 256, 512, 1024):
+                    d = ol.stream_u(f1, (side // 4) ** 2, seed=side)
+                    o = np.empty(side * side * 4, np.uint8)
+                    row["%dx%d_us" % (side, side)] = round(per_call_us(lambda: a.linear(f1, d, side, side, out=o)), 1)
+                small[label] = row
+            result["host_tier_small"] = small
+        except Exception as e:  # noqa
+            log("host_tier_small failed:", e)
 
     if world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(fmt, data, W, H)

@@ -182,6 +182,18 @@ template <class Dec> hipError_t launch_blocks(const BatchArgs &a) {
 	return with_epilogue<Dec>(a.epi, [&](auto epi) { return launch_blocks_epi<Dec, decltype(epi)::value>(a); });
 }
 
+// one block handed over as a kernel argument (kernels_extra.h: decode_single)
+struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; };
+template <class Dec> hipError_t launch_single(const SingleArgs &a) {
+	using Plain = typename PlainDecoder<Dec>::type;
+	typename BlockWord<Dec::kBlockBytes>::type blk;
+	memcpy(&blk, a.bitstring, sizeof blk);
+	return with_epilogue<Dec>(a.epi, [&](auto epi) {
+		hipLaunchKernelGGL((decode_single<Plain, decltype(epi)::value>), dim3(1), dim3(256), 0, a.stream, blk, a.mode_mask, a.flags, a.pixels, a.ok);
+		return hipGetLastError();
+	});
+}
+
 // 8f-3: all levels of a mip chain in one launch (kernels_extra.h)
 struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; };
 template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
@@ -223,16 +235,17 @@ struct FormatEntry {
 	uint32_t texture_format;
 	hipError_t (*linear)(const Geometry &);
 	hipError_t (*blocks)(const BatchArgs &);
+	hipError_t (*single)(const SingleArgs &);
 	hipError_t (*levels)(LevelsArgs &);
 	hipError_t (*histogram)(const void *, size_t, uint32_t *, hipStream_t, bool);
 	const char *kernel_name;
 };
 
-#define FMT(NAME, DEC, CLS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_levels<DEC>, \
+#define FMT(NAME, DEC, CLS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, &launch_levels<DEC>, \
 	&launch_histogram<CLS, DEC::kBlockBytes / 4>, "decode_linear<detexhip::" #DEC }
 
 const FormatEntry kFormats[20] = {
-	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr },
+	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr },
 	FMT(BC1, DecBC1, kClassS3TC), FMT(BC1A, DecBC1A, kClassS3TC), FMT(BC2, DecBC2, kClassS3TCat8), FMT(BC3, DecBC3, kClassS3TCat8),
 	FMT(RGTC1, DecRGTC1, kClassNone), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone), FMT(RGTC2, DecRGTC2, kClassNone),
 	FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone),
@@ -352,6 +365,9 @@ struct ThreadContext {
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
 	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls / histogram bins
+	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
+	uint8_t *h_pin = nullptr, *d_pin = nullptr;
+	size_t pin_cap = 0;
 	void release() {
 		if (!ready) return;
 		int prev = -1;
@@ -359,8 +375,10 @@ struct ThreadContext {
 		(void)hipSetDevice(device);
 		(void)hipStreamSynchronize(stream);
 		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
+		if (h_pin) (void)hipHostFree(h_pin);
 		(void)hipStreamDestroy(stream);
 		d_in = d_out = nullptr; d_status = nullptr; in_cap = out_cap = 0;
+		h_pin = d_pin = nullptr; pin_cap = 0;
 		stream = nullptr;
 		ready = false;
 		if (prev >= 0) (void)hipSetDevice(prev);
@@ -432,6 +450,27 @@ bool reserve(void **buf, size_t *cap, size_t need) {
 	return true;
 }
 
+// Small calls of the host tier (the one-block leaf functions; textures up to Tune::kHostDirectBytes of blocks + pixels): the
+// blocks are placed in a pinned, device-visible host buffer and the kernel reads them from there and writes pixels, ok bytes
+// and the status word back into it -- ONE launch and one stream synchronisation instead of memset + upload + launch + two
+// downloads (five runtime calls that cost more than the kernel's PCIe traffic for a few KiB).  Layout of the buffer:
+// [status word, ok byte: 256 B][blocks, 256-byte aligned][pixels, 256-byte aligned].
+struct DirectExchange { uint8_t *h_base, *d_base; size_t in_off, out_off; };
+bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, DirectExchange *x) {
+	const size_t in_off = 256, out_off = in_off + ((in_bytes + 255) & ~(size_t)255), need = out_off + ((out_bytes + 255) & ~(size_t)255);
+	if (need > c.pin_cap) {
+		if (c.h_pin) HIP_TRY(hipHostFree(c.h_pin), "hipHostFree");
+		c.h_pin = c.d_pin = nullptr; c.pin_cap = 0;
+		const size_t rounded = (need + 65535) & ~(size_t)65535;
+		void *h = nullptr, *d = nullptr;
+		HIP_TRY(hipHostMalloc(&h, rounded, hipHostMallocMapped), "hipHostMalloc");
+		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); detexSetErrorMessage("libdetexhip: hipHostGetDevicePointer failed"); return false; }
+		c.h_pin = static_cast<uint8_t *>(h); c.d_pin = static_cast<uint8_t *>(d); c.pin_cap = rounded;
+	}
+	*x = DirectExchange{ c.h_pin, c.d_pin, in_off, out_off };
+	return true;
+}
+
 // shared by the 19 leaf functions and detexDecompressBlock: one block through the GPU.
 // Returns 1 = decoded, 0 = the decoder returned false, -1 = HIP/runtime failure (message set).
 int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags,
@@ -442,24 +481,20 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	if (!scope.ok) return -1;
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
 	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
-	if (!reserve(&c.d_in, &c.in_cap, 4096) || !reserve(&c.d_out, &c.out_cap, 4096)) return -1;
-	uint8_t *d_ok = reinterpret_cast<uint8_t *>(c.d_status + 1);
-	uint8_t host_out[DETEX_MAX_BLOCK_SIZE];
-	uint8_t ok = 0;
+	DirectExchange x;
+	if (!direct_exchange(c, bs, out_bytes, &x)) return -1;
+	x.h_base[4] = 0;								// the ok byte
 	auto run = [&]() -> bool {
-		HIP_TRY(hipMemcpyAsync(c.d_in, bitstring, bs, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
 		const int epi = prepared_epilogue(f->texture_format, pixel_format);
 		if (epi == -2) return false;
-		BatchArgs a{ c.d_in, c.d_out, 1, mode_mask, flags, d_ok, nullptr, c.stream, true, epi };
-		HIP_TRY(f->blocks(a), "kernel launch");
-		HIP_TRY(hipMemcpyAsync(host_out, c.d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
-		HIP_TRY(hipMemcpyAsync(&ok, d_ok, 1, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+		SingleArgs a{ bitstring, mode_mask, flags, reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi };
+		HIP_TRY(f->single(a), "kernel launch");
 		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 		return true;
 	};
 	if (!run()) return -1;
-	if (!ok) return 0;
-	memcpy(pixel_buffer, host_out, out_bytes);
+	if (!x.h_base[4]) return 0;
+	memcpy(pixel_buffer, x.h_base + x.out_off, out_bytes);
 	return 1;
 }
 
@@ -972,6 +1007,30 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
 	// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
 	const size_t cov_w = tiled ? 0 : (width < 4u * wb ? width : 4u * wb), cov_h = tiled ? 0 : (height < 4u * hb ? height : 4u * hb);
+	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
+		// small texture: the kernel reads the blocks from, and writes pixels and status into, pinned host memory (direct_exchange)
+		DirectExchange x;
+		if (!direct_exchange(c, in_bytes, out_bytes, &x)) return false;
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
+		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
+		int rc;
+		if (tiled)
+			rc = detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st);
+		else
+			rc = detexhipDecompressTextureLinearDevice(texture->format, x.d_base + x.in_off, (int)width, (int)height, (int)wb, (int)hb, x.d_base + x.out_off,
+				width * px, pixel_format, c.stream, d_st);
+		if (rc != 0) return false;
+		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		const uint8_t *res = x.h_base + x.out_off;
+		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
+		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
+			detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+			return false;
+		}
+		return true;
+	}
 	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, out_bytes)) return false;
 	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
 	uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);

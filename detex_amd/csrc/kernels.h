@@ -384,8 +384,8 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 // 4 / 8 / 12 bytes off 16), lost 30-35 % (BC1 8188 x 8192 60.7 us, 8190 x 8190 63-64 us against 43 for 8192 x 8192).
 // Here a workgroup decodes up to 256 blocks of ONE block row, parks the four texel rows in LDS, and then writes each
 // texel row's byte range [x0, x1) of its image row in 16-byte vectors laid on the 64-byte grid of the ADDRESS SPACE (wave w
-// covers the w-th KiB from the sector boundary below the range), whatever the range's own alignment: only the first and the
-// last sector of a 4 KiB piece can be partial.  The image's right and bottom edges are clipped by the range, so clipped
+// covers the w-th KiB from the first sector boundary in the range), whatever the range's own alignment: only the first and
+// the last sector of a 4 KiB piece can be partial, and each is one store instruction.  The image's right and bottom edges are clipped by the range, so clipped
 // textures need no separate edge pass.  Needs rows that are dword-aligned and a whole number of dwords long; anything else
 // (R8 / RG8 / RGB8 images of odd width) goes pixel by pixel through decode_linear_clipped.
 template <class Dec, int EPI>
@@ -431,34 +431,30 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_s
 	for (int r = 0; r < 4; r++) {
 		const uint32_t y = by * 4u + (uint32_t)r;
 		if (y >= height) break;
-		uint8_t *row = pixels + (uint64_t)y * pitch;
-		const uintptr_t g0 = reinterpret_cast<uintptr_t>(row) + x0, g1 = reinterpret_cast<uintptr_t>(row) + x1;
-		const uintptr_t base = g0 & ~(uintptr_t)63;			// the 64-byte grid of the address space
-		const uint32_t lead = (uint32_t)(g0 - base);			// 0 .. 60, a multiple of 4
-		const uint32_t n_chunks = (uint32_t)((g1 - base + 15u) >> 4);	// <= 256 * ROW / 4 + 4
-		const uint8_t *staged = reinterpret_cast<const uint8_t *>(&stage[r][SLACK]);
-		for (uint32_t c = threadIdx.x; c < n_chunks; c += 256u) {
-			const uintptr_t lo = base + 16u * c;
-			if (lo + 16u <= g0) continue;						// (up to three vectors of the first sector lie in front of the range)
-			const int32_t src = (int32_t)(16u * c) - (int32_t)lead;		// byte offset into the staged row; >= -12 here
-			// the two aligned 16-byte LDS vectors that contain the chunk (the slack keeps both inside the array)
-			const uint32_t shift = (uint32_t)src & 12u;
-			const v4 *q = reinterpret_cast<const v4 *>(staged + ((src - (int32_t)shift)));
+		uint8_t *out = pixels + (uint64_t)y * pitch + x0;			// the tile's piece of image row y: n bytes, dword-aligned
+		const uint32_t *staged = &stage[r][SLACK];
+		const uint32_t n = x1 - x0;
+		// [head: up to the first 64-byte boundary][body: whole sectors][tail].  Head and tail are each written by ONE
+		// dword-store instruction (lane k its k-th dword), so a boundary sector receives one partial write from this workgroup
+		// and one from its neighbour -- per-dword instructions made every one of them a partial write of its own.
+		const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 63u);
+		const uint32_t head = lead ? (64u - lead < n ? 64u - lead : n) : 0u;
+		const uint32_t body = (n - head) & ~63u, tail = n - head - body;
+		if (threadIdx.x < head / 4u) __builtin_nontemporal_store(staged[threadIdx.x], reinterpret_cast<uint32_t *>(out) + threadIdx.x);
+		if (threadIdx.x >= 64u && threadIdx.x - 64u < tail / 4u)
+			__builtin_nontemporal_store(staged[(head + body) / 4u + threadIdx.x - 64u], reinterpret_cast<uint32_t *>(out + head + body) + (threadIdx.x - 64u));
+		const uint32_t shift = head & 12u;					// the body's position in the staged row modulo 16
+		for (uint32_t c = threadIdx.x; c < body / 16u; c += 256u) {
+			const uint32_t src = head + 16u * c;				// byte offset into the staged row
+			// the two aligned 16-byte LDS vectors that contain the chunk (the slack keeps the second inside the array)
+			const v4 *q = reinterpret_cast<const v4 *>(reinterpret_cast<const uint8_t *>(staged) + (src - shift));
 			const v4 a = q[0], b = q[1];
-			const uint32_t cat[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-			uint32_t d[4];
-			// (shift is the same for every chunk of the row: lead is)
-			if (shift == 0u) { d[0] = cat[0]; d[1] = cat[1]; d[2] = cat[2]; d[3] = cat[3]; }
-			else if (shift == 4u) { d[0] = cat[1]; d[1] = cat[2]; d[2] = cat[3]; d[3] = cat[4]; }
-			else if (shift == 8u) { d[0] = cat[2]; d[1] = cat[3]; d[2] = cat[4]; d[3] = cat[5]; }
-			else { d[0] = cat[3]; d[1] = cat[4]; d[2] = cat[5]; d[3] = cat[6]; }
-			if (lo >= g0 && lo + 16u <= g1) {
-				__builtin_nontemporal_store(v4{ d[0], d[1], d[2], d[3] }, reinterpret_cast<v4 *>(lo));
-			} else {
-#pragma unroll
-				for (int k = 0; k < 4; k++)
-					if (lo + 4u * k >= g0 && lo + 4u * k + 4u <= g1) __builtin_nontemporal_store(d[k], reinterpret_cast<uint32_t *>(lo + 4u * k));
-			}
+			v4 d;
+			if (shift == 0u) d = a;
+			else if (shift == 4u) d = v4{ a.y, a.z, a.w, b.x };
+			else if (shift == 8u) d = v4{ a.z, a.w, b.x, b.y };
+			else d = v4{ a.w, b.x, b.y, b.z };
+			__builtin_nontemporal_store(d, reinterpret_cast<v4 *>(out + src));
 		}
 	}
 }

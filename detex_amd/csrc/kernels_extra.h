@@ -25,6 +25,26 @@ struct LevelTable {
 	LevelDesc level[kMaxLevels];
 };
 
+// ---- one block, for the reference's per-block entry points (detexDecompressBlock<FMT>, detex.h:435-531) -----------------------
+// The block travels as a KERNEL ARGUMENT and the sixteen pixels + the decoder's bool go straight into pinned host memory: a
+// call is one launch and one synchronisation, with no read across PCIe at all (the batched kernel fetching its single block
+// from host memory measured 19.8 us per call, upload + launch + two downloads 16.7).  Every lane decodes the same block (the
+// table copy and the per-lane LDS rows of the BPTC decoders want the whole workgroup); lane 0 stores.
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256) void decode_single(const typename BlockWord<Dec::kBlockBytes>::type blk, uint32_t mode_mask, uint32_t flags,
+		uint32_t *__restrict__ pixels, uint8_t *__restrict__ ok_out) {
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
+	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
+	uint32_t o[4 * ROW];
+	const bool ok = decode_word<Dec, EPI, true>(blk, mode_mask, flags, o);
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int k = 0; k < 4 * ROW; k++) pixels[k] = o[k];
+		*ok_out = ok ? 1 : 0;
+	}
+}
+
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;

@@ -25,6 +25,9 @@ struct ProductTune {
 	static constexpr bool kMasksInVgprs = true;
 	// RGTC1: blocks per lane in the linear kernel
 	static constexpr int kRgtc1LaneBlocks = 4;
+	// host-pointer tier: textures whose blocks + pixels fit in this many bytes are exchanged through pinned host memory the
+	// kernel reads and writes directly (one launch + one synchronisation; detexhip.hip: direct_exchange)
+	static constexpr unsigned long kHostDirectBytes = 1280u << 10;	// up to 512 x 512 RGBA8 (measured: 64^2 51 -> 18 us, 256^2 83 -> 31 us per call)
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };

@@ -3,9 +3,9 @@
 The decode itself needs no exchange: blocks are stored row-major (texture.c:115-141) and the
 linear image is row-major with pitch width*px (texture.c:129-131), so the shard of rank g --
 block rows [g*hb/G, (g+1)*hb/G) -- is ONE contiguous byte range of the input and ONE contiguous
-byte range of the output.  The only collective on this path is the optional whole-image gather
-(all_gather of variable-size row bands, done as equal-size padded chunks or per-rank broadcasts),
-used by callers that want the full image on every rank; decode throughput never includes it.
+byte range of the output.  The only communication on this path is the optional whole-image gather: to one rank (gather_image_to_root: grouped
+point-to-point sends straight into the root's image) or to every rank (gather_image: one all_gather_into_tensor);
+decode throughput never includes it.
 """
 from collections import namedtuple
 
@@ -81,3 +81,37 @@ def gather_image(dist, torch, fmt, width, height, shard, local_pixels, local_ok=
             out[s.out_offset:s.out_offset + s.out_bytes] = image[r * chunk:r * chunk + s.out_bytes]
         image = out
     return bool(flag.item()), image
+
+
+def gather_image_to_root(dist, torch, fmt, width, height, shard, local_pixels, local_ok=True, root=0, group=None, image=None):
+    """Optional whole-image gather to ONE rank: every other rank sends its band straight into its place in
+    the root's image -- grouped point-to-point transfers (ncclSend / ncclRecv inside one group on the GPU box, so the
+    root's xGMI links to all peers carry data at once; gloo in the CPU tests), no staging copy, bands of any (unequal)
+    size.  Only 1/world of what an all-gather moves crosses each link, and nothing lands on the other ranks.
+    Returns (ok, image) on the root -- ok = AND of the per-rank flags, the reference's bool result (texture.c:144) --
+    and (ok, None) elsewhere.  `image` may be a preallocated width*height*px uint8 tensor on the root."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    px = fmt.pixel_bytes
+    dev = local_pixels.device
+    flat = local_pixels.reshape(-1)[:shard.out_bytes]
+    ops = []
+    if rank == root:
+        if image is None or image.numel() != width * height * px:
+            image = torch.empty(width * height * px, dtype=torch.uint8, device=dev)
+        for r in range(world):
+            s = shard_of(r, world, fmt, width, height)
+            if s.out_bytes == 0:
+                continue
+            if r == root:
+                image[s.out_offset:s.out_offset + s.out_bytes] = flat
+            else:
+                ops.append(dist.P2POp(dist.irecv, image[s.out_offset:s.out_offset + s.out_bytes], r, group))
+    elif shard.out_bytes:
+        ops.append(dist.P2POp(dist.isend, flat.contiguous(), root, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item()), (image if rank == root else None)

@@ -180,6 +180,11 @@ def _gloo_worker(rank, world, port, q):
             ok_all, image = sharding.gather_image(dist, torch, fmt, w, h, shard, local, ok)
             ok_ref, want = orc.linear(fmt, data, w, h)
             results.append((name, ok_all == ok_ref, bool(np.array_equal(image.numpy(), want))))
+            # the same image gathered to one rank only (the last one, to exercise root != 0): grouped sends / receives
+            root = world - 1
+            ok_root, image_root = sharding.gather_image_to_root(dist, torch, fmt, w, h, shard, local, ok, root=root)
+            results.append((name + " to root", ok_root == ok_ref,
+                            bool(np.array_equal(image_root.numpy(), want)) if rank == root else image_root is None))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, results))

@@ -11,6 +11,7 @@
 #   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
 #   sgprconst               v_bitop3 masks left in SGPRs
 #   rgtc1gN                 RGTC1 blocks per lane
+#   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
 #   planarN                 ETC2: most planar blocks per wave decoded cooperatively (0 = always in-lane)
 #   several joined by '+':  nostore+prio1
 set -e
@@ -34,6 +35,7 @@ for v in "$@"; do
       bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;
       sgprconst) body+="static constexpr bool kMasksInVgprs = false; " ;;
       rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
+      hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
       planar*) body+="static constexpr int kEtcPlanarShared = ${k#planar}; " ;;
       *) echo "unknown knob $k" >&2; exit 2 ;;
     esac

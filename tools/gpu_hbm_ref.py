@@ -35,6 +35,10 @@ for (wbytes, h) in ((32768, 8192), (65536, 8192), (65536, 16384)):
     for pat in (0, 2):
         gbps, us = hbmref.fill_image_GBps(wbytes, h, pat, 30)
         emit({"op": "fill_image", "width_bytes": wbytes, "height": h, "MiB": wbytes * h >> 20, "pattern": pat, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
+# ... with padded row pitches: what the memory system makes of an image whose rows are not a power of two apart
+for pad in (0, 64, 128, 256, 4096 + 64, 16, 32, 48):
+    gbps, us = hbmref.fill_image_GBps(32768, 8192, 2, 60, 32768 + pad)
+    emit({"op": "fill_image_pitch", "width_bytes": 32768, "height": 8192, "pitch": 32768 + pad, "pitch_mod_64": pad % 64, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
 for off in (0, 4, 8, 12, 16, 32, 48, 64, 112):
     gbps, us = hbmref.fill_unaligned_GBps(256 << 20, off, 30)
     emit({"op": "fill_dword_aligned_stores", "MiB": 256, "offset": off, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})

@@ -17,7 +17,7 @@ def load():
         lib.hbmref_fill.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
         lib.hbmref_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         lib.hbmref_fill_unaligned.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
-        lib.hbmref_fill_image.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+        lib.hbmref_fill_image.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -67,16 +67,16 @@ def copy_GBps(nbytes, nontemporal=True, launches=30):
     return 2 * nbytes / (us * 1e-6) / 1e9, us
 
 
-def fill_image_GBps(width_bytes, height, pattern=2, launches=30):
-    """write-only fill in the decode kernels' image layout (four 4 KiB row pieces per workgroup)"""
+def fill_image_GBps(width_bytes, height, pattern=2, launches=30, pitch_bytes=0):
+    """write-only fill in the decode kernels' image layout (four 4 KiB row pieces per workgroup); bytes written per second"""
     import torch
     lib = load()
     nbytes = width_bytes * height
-    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    buf = torch.empty((pitch_bytes or width_bytes) * height, dtype=torch.uint8, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        if lib.hbmref_fill_image(buf.data_ptr(), width_bytes, height, pattern, 7, st) != 0:
+        if lib.hbmref_fill_image(buf.data_ptr(), width_bytes, height, pitch_bytes, pattern, 7, st) != 0:
             raise RuntimeError("hbmref_fill_image failed")
     us = time_us(step, launches)
     return nbytes / (us * 1e-6) / 1e9, us

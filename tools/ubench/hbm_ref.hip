@@ -109,10 +109,12 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill_unaligned(void
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// width_bytes x height image (width a multiple of 4096 bytes, height of 4 rows), pattern 0 or 2
-extern "C" __attribute__((visibility("default"))) int hbmref_fill_image(void *dst, size_t width_bytes, size_t height, int pattern, uint32_t seed, void *stream) {
-	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
-	const uint32_t tiles_per_row = (uint32_t)(width_bytes / 4096u), pitch_vectors = (uint32_t)(width_bytes / 16u);
+// width_bytes x height image (width a multiple of 4096 bytes, height of 4 rows), rows pitch_bytes apart (0 = dense; a multiple
+// of 16), pattern 0 or 2
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_image(void *dst, size_t width_bytes, size_t height, size_t pitch_bytes, int pattern, uint32_t seed, void *stream) {
+	if (pitch_bytes == 0) pitch_bytes = width_bytes;
+	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || pitch_bytes % 16u || pitch_bytes < width_bytes || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const uint32_t tiles_per_row = (uint32_t)(width_bytes / 4096u), pitch_vectors = (uint32_t)(pitch_bytes / 16u);
 	const dim3 grid((unsigned)(tiles_per_row * (height / 4u))), block(256);
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (pattern == 0) hipLaunchKernelGGL((fill_image_kernel<0>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
