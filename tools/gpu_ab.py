@@ -92,8 +92,18 @@ for fname in args.formats.split(","):
                         break
                     prev = us
                 if args.clocks:
+                    # keep the kernel running for ~3 s so the sampler (one rocm-smi call takes ~0.3 s) sees the settled state
+                    t_end = time.time() + 3.0
+                    while time.time() < t_end:
+                        for _ in range(200):
+                            step()
+                        torch.cuda.synchronize()
                     stop[0] = True; t.join()
-                    clocks[spec] = samples[-3:]
+                    tail = [x for x in samples[len(samples) // 2:] if "sclk" in x]
+                    mhz = [int("".join(ch for ch in x["sclk"] if ch.isdigit())) for x in tail]
+                    watts = [float(x["W"]) for x in tail if "W" in x]
+                    clocks[spec] = {"samples": len(tail), "sclk_MHz_mean": round(sum(mhz) / max(1, len(mhz))), "sclk_MHz_min": min(mhz or [0]), "sclk_MHz_max": max(mhz or [0]),
+                                    "W_mean": round(sum(watts) / max(1, len(watts))), "W_max": max(watts or [0])}
                 results[spec].append(round(us, 2))
         for spec, _, _ in libs:
             if not results[spec]:
