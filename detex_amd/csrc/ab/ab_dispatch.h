@@ -37,21 +37,21 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 	}
 	if constexpr (EPI == kEpiNone) {
 		if (g.variant == 2) {
-			hipLaunchKernelGGL((decode_linear<typename PlainDecoder<Dec>::type, kEpiNone, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			hipLaunchKernelGGL((decode_linear<typename PlainDecoder<Dec>::type, kEpiNone, false>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, 0u);
 			*result = hipGetLastError();
 			return true;
 		}
 	}
 	if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder<Dec>::type, Dec>) {
 		if (g.variant == 3) {
-			hipLaunchKernelGGL((decode_linear<typename AltDecoder<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			hipLaunchKernelGGL((decode_linear<typename AltDecoder<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, 0u);
 			*result = hipGetLastError();
 			return true;
 		}
 	}
 	if constexpr (EPI == kEpiNone && !std::is_same_v<typename AltDecoder2<Dec>::type, Dec>) {
 		if (g.variant == 4) {
-			hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+			hipLaunchKernelGGL((decode_linear<typename AltDecoder2<Dec>::type, kEpiNone, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, 0u);
 			*result = hipGetLastError();
 			return true;
 		}

@@ -7,6 +7,14 @@
 
 namespace detexhip {
 
+// Spec-conformance switches, carried in the upper bits of the decoders' `flags` argument (the reference's own flags are
+// bits 0-2, detex.h:397-411): the reference differs from the BPTC specification in two places, which
+// the decoders reproduce unless these are set (detexhipSetQuirks clears the corresponding quirk).
+enum : uint32_t {
+	kFlagSpecBc7Mode6PBit = 1u << 30,	// BC7 mode 6: the second endpoint's P-bit is read from block bit 64 (the reference reads 0)
+	kFlagSpecBc6hMode12Bit63 = 1u << 31,	// BC6H mode 12: block bit 63 (b0[11]) is used (the reference build drops it)
+};
+
 // [0..63] two-subset partitions, [64..127] three-subset partitions; 2-bit subset field per texel
 __constant__ uint32_t kPartition2Bit[128] = { DETEXHIP_P2X_WORDS, DETEXHIP_P3_WORDS };
 // anchor2 | anchor3_second << 4 | anchor3_third << 8

@@ -333,7 +333,7 @@ template <int FIXED> struct Bc7RecReader {
 };
 
 template <int FIXED>
-DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t (&d)[16]) {
+DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t flags, uint32_t (&d)[16]) {
 	constexpr Bc7Rec kFixed = kBc7RecTableCx.r[FIXED >= 0 ? FIXED : 0];
 	const Bc7RecReader<FIXED> L(rec_index);
 	typedef Bc7Lane::Group Group;
@@ -371,7 +371,8 @@ DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t (&d)[16]) {
 	const uint32_t wr = lane.field(g_row.x, g_pos.x), wg = lane.field(g_row.y, g_pos.y), wb = lane.field(g_row.z, g_pos.z);
 	const uint32_t wa = wave_alpha ? lane.field(g_row.w, g_pos.w) : 0u;
 	L.pin(g_p, g_c, g_ba, g_pi, g_pj);
-	const uint32_t pw = lane.field(g_p.x, g_p.y) & g_p.z;
+	// QUIRK A-2 lives in the record's P-word mask (mode 6: only the first P-bit survives); the spec switch, wave-uniform, lifts it
+	const uint32_t pw = lane.field(g_p.x, g_p.y) & (g_p.z | ((flags & kFlagSpecBc7Mode6PBit) ? 0xFFFFFFFFu : 0u));
 	const uint32_t cb = g_p.w, ab = g_c.x;
 	const uint32_t pidx[6] = { g_pi.x, g_pi.y, g_pi.z, g_pi.w, g_pj.x, g_pj.y };
 	uint32_t off = 0u, offa = 0u;
@@ -533,20 +534,20 @@ template <bool UNIFORM> struct DecBPTCT {
 			const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 			if (__builtin_amdgcn_ballot_w64(r != r0) == 0) {
 				switch (r0) {
-				case 0: bc7_decode_with<0>(blk, r, d); return valid;
-				case 1: bc7_decode_with<1>(blk, r, d); return valid;
-				case 2: bc7_decode_with<2>(blk, r, d); return valid;
-				case 3: bc7_decode_with<3>(blk, r, d); return valid;
-				case 4: bc7_decode_with<4>(blk, r, d); return valid;
-				case 5: bc7_decode_with<5>(blk, r, d); return valid;
-				case 6: bc7_decode_with<6>(blk, r, d); return valid;
-				case 7: bc7_decode_with<7>(blk, r, d); return valid;
-				default: bc7_decode_with<8>(blk, r, d); return valid;
+				case 0: bc7_decode_with<0>(blk, r, flags, d); return valid;
+				case 1: bc7_decode_with<1>(blk, r, flags, d); return valid;
+				case 2: bc7_decode_with<2>(blk, r, flags, d); return valid;
+				case 3: bc7_decode_with<3>(blk, r, flags, d); return valid;
+				case 4: bc7_decode_with<4>(blk, r, flags, d); return valid;
+				case 5: bc7_decode_with<5>(blk, r, flags, d); return valid;
+				case 6: bc7_decode_with<6>(blk, r, flags, d); return valid;
+				case 7: bc7_decode_with<7>(blk, r, flags, d); return valid;
+				default: bc7_decode_with<8>(blk, r, flags, d); return valid;
 				}
 			}
 		}
 #endif
-		bc7_decode_with<-1>(blk, r, d);
+		bc7_decode_with<-1>(blk, r, flags, d);
 		return valid;
 	}
 };

@@ -95,8 +95,9 @@ template <int M, int S> DH void bc6h_scatter(const Bits128 &b, uint32_t (&ep)[3]
 }
 
 struct Bc6hParams { uint32_t epb, dr, dg, db; };
-template <int M> DH Bc6hParams bc6h_mode(Bits128 b, uint32_t (&ep)[3][4]) {
-	if constexpr (M == 12) b.w[1] &= 0x7FFFFFFFu;	// QUIRK A-3: block bit 63 dropped (decompress-bptc-float.c:462)
+template <int M> DH Bc6hParams bc6h_mode(Bits128 b, uint32_t flags, uint32_t (&ep)[3][4]) {
+	// QUIRK A-3: block bit 63 dropped (decompress-bptc-float.c:462) unless the spec switch is set
+	if constexpr (M == 12) b.w[1] &= (flags & kFlagSpecBc6hMode12Bit63) ? 0xFFFFFFFFu : 0x7FFFFFFFu;
 	bc6h_scatter<M, 0>(b, ep);
 	return Bc6hParams{ (uint32_t)kBc6hEpb[M], (uint32_t)kBc6hDelta[M][0], (uint32_t)kBc6hDelta[M][1], (uint32_t)kBc6hDelta[M][2] };
 }
@@ -257,14 +258,15 @@ struct Bc6hLane {
 };
 #endif
 
-DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t (&ep)[3][4]) {
+DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t flags, uint32_t (&ep)[3][4]) {
 	const Bc6hModeWords mw = bc6h_mode_words(mode);
 	const uint32_t w0 = mw.a & 15u, rw = ubfe(mw.a, 4, 4), gw = ubfe(mw.a, 8, 4), bw = ubfe(mw.a, 12, 4);
 	const bool transformed = (mw.a >> 21) & 1u, one = mode >= 10u;
 	// main fields at their canonical positions, per-lane widths
 	const uint32_t win35 = field_at<35, 32>(b), win45 = field_at<45, 32>(b);
 	uint32_t win55 = field_at<55, 32>(b);
-	win55 = mode == 12u ? (win55 & ~0x100u) : win55;	// QUIRK A-3: block bit 63 (b0[11] of mode 12) reads 0
+	// QUIRK A-3: block bit 63 (b0[11] of mode 12) reads 0 -- unless the (wave-uniform) spec switch is set
+	win55 = mode == 12u ? (win55 & ~((flags & kFlagSpecBc6hMode12Bit63) ? 0u : 0x100u)) : win55;
 	ep[0][0] = ubfe(field_at<5, 10>(b), 0, w0);
 	ep[1][0] = ubfe(field_at<15, 10>(b), 0, w0);
 	ep[2][0] = ubfe(field_at<25, 10>(b), 0, w0);
@@ -346,7 +348,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	// the caller's zero-fill of a failed block (32 moves that nearly every wave of a random stream executes: one block in
 	// sixteen carries a reserved mode) is not needed (kernels.h: decode_word)
 	static constexpr bool kZeroOnFailure = true;
-	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t, uint32_t (&d)[32]) {
+	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[32]) {
 		// :23-33: 2-bit codes 00/01 = modes 0/1, otherwise a 5-bit code; 10011,10111,11011,11111 reserved
 		stage_priority<Tune::kBc6hPrio, 0>();
 		const uint32_t low2 = blk.x & 3u, low5 = blk.x & 0x1Fu;
@@ -358,22 +360,22 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		const Bits128 b = { { blk.x, blk.y, blk.z, blk.w } };
 		uint32_t ep[3][4] = {};
 		Bc6hParams p;
-		if (!SWITCH_SCATTER) p = bc6h_scatter_generic(b, mode, ep);
+		if (!SWITCH_SCATTER) p = bc6h_scatter_generic(b, mode, flags, ep);
 		else switch (mode) {
-		case 0: p = bc6h_mode<0>(b, ep); break;
-		case 1: p = bc6h_mode<1>(b, ep); break;
-		case 2: p = bc6h_mode<2>(b, ep); break;
-		case 3: p = bc6h_mode<3>(b, ep); break;
-		case 4: p = bc6h_mode<4>(b, ep); break;
-		case 5: p = bc6h_mode<5>(b, ep); break;
-		case 6: p = bc6h_mode<6>(b, ep); break;
-		case 7: p = bc6h_mode<7>(b, ep); break;
-		case 8: p = bc6h_mode<8>(b, ep); break;
-		case 9: p = bc6h_mode<9>(b, ep); break;
-		case 10: p = bc6h_mode<10>(b, ep); break;
-		case 11: p = bc6h_mode<11>(b, ep); break;
-		case 12: p = bc6h_mode<12>(b, ep); break;
-		default: p = bc6h_mode<13>(b, ep); break;
+		case 0: p = bc6h_mode<0>(b, flags, ep); break;
+		case 1: p = bc6h_mode<1>(b, flags, ep); break;
+		case 2: p = bc6h_mode<2>(b, flags, ep); break;
+		case 3: p = bc6h_mode<3>(b, flags, ep); break;
+		case 4: p = bc6h_mode<4>(b, flags, ep); break;
+		case 5: p = bc6h_mode<5>(b, flags, ep); break;
+		case 6: p = bc6h_mode<6>(b, flags, ep); break;
+		case 7: p = bc6h_mode<7>(b, flags, ep); break;
+		case 8: p = bc6h_mode<8>(b, flags, ep); break;
+		case 9: p = bc6h_mode<9>(b, flags, ep); break;
+		case 10: p = bc6h_mode<10>(b, flags, ep); break;
+		case 11: p = bc6h_mode<11>(b, flags, ep); break;
+		case 12: p = bc6h_mode<12>(b, flags, ep); break;
+		default: p = bc6h_mode<13>(b, flags, ep); break;
 		}
 		const bool two = mode < 10u;
 		// a wave of one-subset blocks only (modes 10-13: what encoders emit for smooth HDR content) does not

@@ -69,7 +69,7 @@ namespace {
 
 struct Geometry {
 	const void *blocks; void *pixels; uint32_t wb, hb, width, height; uint64_t pitch;
-	uint32_t *status; hipStream_t stream; int variant; int epi;
+	uint32_t *status; hipStream_t stream; int variant; int epi; uint32_t decode_flags;
 };
 struct BatchArgs {
 	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
@@ -135,12 +135,12 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 		if constexpr (kGroup > 1) {
 			if (g.wb % kGroup == 0 && (reinterpret_cast<uintptr_t>(px) | g.pitch) % (4u * kRow * kGroup) == 0) {
 				hipLaunchKernelGGL((decode_linear_grouped<Dec, EPI, true, kGroup>), dim3((n / kGroup + 255u) / 256u), dim3(256), 0, g.stream,
-					g.blocks, px, g.wb, n, g.pitch, g.status);
+					g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
 				return hipGetLastError();
 			}
 		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
-		hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
+		hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
 		return hipGetLastError();
 	}
 	// Everything else whose rows are dword-aligned and a whole number of dwords long -- clipped sizes (texture.c:116-120,
@@ -151,10 +151,10 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 	if (((reinterpret_cast<uintptr_t>(px) | (uintptr_t)g.pitch | row_bytes) & 3u) == 0 && row_bytes <= 0xFFFFFFFFull) {
 		const uint32_t tiles_per_row = (g.wb + 255u) / 256u;
 		hipLaunchKernelGGL((decode_linear_staged<Plain, EPI>), dim3(tiles_per_row * g.hb), dim3(256), 0, g.stream, g.blocks, px, g.wb, (uint32_t)row_bytes,
-			g.height, g.pitch, g.status, tiles_per_row);
+			g.height, g.pitch, g.status, tiles_per_row, g.decode_flags);
 	} else {
 		hipLaunchKernelGGL((decode_linear_clipped<Plain, EPI>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.width, g.height, g.pitch,
-			g.status);
+			g.status, g.decode_flags);
 	}
 	return hipGetLastError();
 }
@@ -195,7 +195,7 @@ template <class Dec> hipError_t launch_single(const SingleArgs &a) {
 }
 
 // 8f-3: all levels of a mip chain in one launch (kernels_extra.h)
-struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; };
+struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; uint32_t decode_flags; };
 template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
 	constexpr unsigned row_bytes = 4u * EpilogueOf<Dec, EPI>::kRowDwords;
 	constexpr unsigned align = row_bytes % 16u == 0 ? 16u : (row_bytes % 8u == 0 ? 8u : 4u);
@@ -207,7 +207,7 @@ template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
 	}
 	const uint32_t grid = a.table.wg_start[a.table.n_levels];
 	if (grid == 0) return hipSuccess;
-	hipLaunchKernelGGL((decode_levels<typename PlainDecoder<Dec>::type, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status);
+	hipLaunchKernelGGL((decode_levels<typename PlainDecoder<Dec>::type, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status, a.decode_flags);
 	return hipGetLastError();
 }
 template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
@@ -361,6 +361,7 @@ struct ThreadContext {
 	bool ready = false;
 	int device = -1;
 	int variant = -1;
+	int quirks = -1;		// detexhipSetQuirks; -1 = not read yet (DETEXHIP_QUIRKS, default all)
 	hipStream_t stream = nullptr;
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
@@ -440,6 +441,17 @@ int current_variant() {
 	return c.variant;
 }
 
+// the reference's two BPTC quirks are reproduced unless switched off for the calling thread
+// (detexhipSetQuirks, or DETEXHIP_QUIRKS in the environment when the thread first decodes); returns the decoders' spec flags
+uint32_t current_spec_flags() {
+	ThreadContext &c = t_ctx;
+	if (c.quirks < 0) {
+		const char *env = getenv("DETEXHIP_QUIRKS");
+		c.quirks = env ? (int)(strtoul(env, nullptr, 0) & DETEXHIP_QUIRKS_REFERENCE) : (int)DETEXHIP_QUIRKS_REFERENCE;
+	}
+	return ((c.quirks & DETEXHIP_QUIRK_BC7_MODE6_PBIT) ? 0u : kFlagSpecBc7Mode6PBit) | ((c.quirks & DETEXHIP_QUIRK_BC6H_MODE12_BIT63) ? 0u : kFlagSpecBc6hMode12Bit63);
+}
+
 bool reserve(void **buf, size_t *cap, size_t need) {
 	if (need <= *cap) return true;
 	if (*buf) HIP_TRY(hipFree(*buf), "hipFree");
@@ -487,7 +499,7 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	auto run = [&]() -> bool {
 		const int epi = prepared_epilogue(f->texture_format, pixel_format);
 		if (epi == -2) return false;
-		SingleArgs a{ bitstring, mode_mask, flags, reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi };
+		SingleArgs a{ bitstring, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi };
 		HIP_TRY(f->single(a), "kernel launch");
 		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 		return true;
@@ -529,6 +541,9 @@ extern "C" uint8_t detexhipHalfFloatToUNorm8(uint16_t half_bits) { return half_t
 
 extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.2 (gfx950; detex v0.1.2 block-decode ABI)"; }
 
+extern "C" void detexhipSetQuirks(uint32_t quirks) { t_ctx.quirks = (int)(quirks & DETEXHIP_QUIRKS_REFERENCE); }
+extern "C" uint32_t detexhipGetQuirks(void) { (void)current_spec_flags(); return (uint32_t)t_ctx.quirks; }
+
 extern "C" void detexhipSetKernelVariant(int variant) { t_ctx.variant = (variant >= 0 && variant <= kMaxVariant) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }
 
@@ -552,7 +567,7 @@ extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, con
 	if (n_levels < 0 || n_levels > kMaxLevels || (n_levels > 0 && !levels)) { detexSetErrorMessage("%s: 0..%d levels per call", who, kMaxLevels); return 1; }
 	const size_t px = (size_t)detexGetPixelSize(pixel_format), palign = px == 3 ? 1 : (px < 4 ? px : 4);
 	LevelsArgs a{};
-	a.status = d_status; a.stream = static_cast<hipStream_t>(stream); a.epi = epi;
+	a.status = d_status; a.stream = static_cast<hipStream_t>(stream); a.epi = epi; a.decode_flags = current_spec_flags();
 	a.table.n_levels = (uint32_t)n_levels;
 	uint32_t wg = 0;
 	for (int l = 0; l < n_levels; l++) {
@@ -623,7 +638,7 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 	const int epi = prepared_epilogue(texture_format, pixel_format);
 	if (epi == -2) return 1;
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
-		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epi };
+		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epi, current_spec_flags() };
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -639,7 +654,8 @@ static int blocks_device(const char *who, uint32_t texture_format, const void *d
 			(int)detexGetCompressedBlockSize(texture_format));
 		return 1;
 	}
-	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, flags, d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi };
+	// the reference's flags occupy bits 0-2 (detex.h:397-411); the spec switches ride in bits 30-31
+	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi };
 	hipError_t e = f->blocks(a);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;

@@ -298,6 +298,9 @@ template <class Dec> DH typename BlockWord<Dec::kBlockBytes>::type load_block(co
 	return blk;
 }
 
+// `decode_flags` of the texture-driver kernels: not the reference's flags (its drivers pass none, texture.c:88,123) but this
+// library's spec-conformance switches for the two BPTC quirks (bptc_common.h: kFlagSpec...; detexhipSetQuirks), a wave-uniform
+// kernel argument that every other decoder ignores.
 // decode + zero-fill on failure + epilogue; returns ok
 template <class Dec, int EPI, bool CHECKED>
 DH bool decode_word(const typename BlockWord<Dec::kBlockBytes>::type &blk, uint32_t mode_mask, uint32_t flags,
@@ -340,7 +343,7 @@ DH bool stores_enabled(const uint32_t *o) {
 template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
-		uint32_t *__restrict__ status) {
+		uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
 	prepare_tables<Dec>();
@@ -356,14 +359,14 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		const bool live = i < n_blocks;
 		uint32_t o[4 * ROW];
 		bool ok = true;
-		if (live) ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+		if (live) ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, decode_flags, o);
 		if (stores_enabled(o))
 			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
 		if (live) raise_status(!ok, status);
 	} else {
 		if (i >= n_blocks) return;
 		uint32_t o[4 * ROW];
-		const bool ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+		const bool ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, decode_flags, o);
 		uint32_t by, bx;
 		split_index(i, width_in_blocks, by, bx);
 		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_staged(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t row_bytes, uint32_t height, uint64_t pitch,
-		uint32_t *__restrict__ status, uint32_t tiles_per_row) {
+		uint32_t *__restrict__ status, uint32_t tiles_per_row, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	constexpr uint32_t PIECE = 4u * ROW;				// bytes of one block in one texel row
 	constexpr uint32_t SLACK = 8u, ROW_DWORDS = 256u * ROW + 2u * SLACK;	// a staged texel row: 32 bytes of slack in front and behind
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_s
 	uint32_t o[4 * ROW];
 	bool ok = true;
 	if (live) {
-		ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, 0u, o);
+		ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, decode_flags, o);
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			uint32_t *slot = &stage[r][SLACK + threadIdx.x * ROW];
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_s
 // falls back to decode_linear otherwise.
 template <class Dec, int EPI, bool NT, int G>
 __global__ __launch_bounds__(256) void decode_linear_grouped(const void *__restrict__ blocks, uint8_t *__restrict__ pixels,
-		uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch, uint32_t *__restrict__ status) {
+		uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch, uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	static_assert(ROW * G == 2 || ROW * G == 4, "a lane writes one 8- or 16-byte vector per texel row");
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(256) void decode_linear_grouped(const void *__restr
 	uint32_t o[G][4 * ROW];
 	bool ok = true;
 #pragma unroll
-	for (int g = 0; g < G; g++) ok &= decode_word<Dec, EPI, false>(blk[g], 0xFFFFFFFFu, 0u, o[g]);
+	for (int g = 0; g < G; g++) ok &= decode_word<Dec, EPI, false>(blk[g], 0xFFFFFFFFu, decode_flags, o[g]);
 	uint32_t by, bx;
 	split_index(first, width_in_blocks, by, bx);
 	uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
@@ -522,14 +525,14 @@ template <int ROW> DH void store_pixel(uint8_t *dst, const uint32_t *row, int x)
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint32_t width,
-		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status) {
+		uint32_t height, uint64_t pitch, uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_blocks) return;
 	uint32_t o[4 * ROW];
-	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, 0u, o);
+	const bool ok = decode_block<Dec, EPI, false>(blocks, i, 0xFFFFFFFFu, decode_flags, o);
 	uint32_t by, bx;
 	split_index(i, width_in_blocks, by, bx);
 	// blocks that lie completely inside the image write whole texel rows when rows are dword-aligned (vector stores

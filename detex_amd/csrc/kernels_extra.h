@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void decode_single(const typename BlockWord<De
 }
 
 template <class Dec, int EPI>
-__global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status) {
+__global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 			const bool live = i < lv.n_blocks;
 			uint32_t o[4 * ROW];
 			bool ok = true;
-			if (live) ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
+			if (live) ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, decode_flags, o);
 			store_rows_wide_pixels(lv.pixels, lv.pitch, lv.width_in_blocks, i - (threadIdx.x & 63u), lv.n_blocks, live, o);
 			if (live) raise_status(!ok, status);
 			return;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	}
 	if (i >= lv.n_blocks) return;
 	uint32_t o[4 * ROW];
-	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, 0u, o);
+	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, decode_flags, o);
 	uint32_t by, bx;
 	split_index(i, lv.width_in_blocks, by, bx);
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);

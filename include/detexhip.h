@@ -175,6 +175,18 @@ DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *
  * (the kernels use a device table built from it); exposed so the table can be checked without a GPU. */
 DETEXHIP_API uint8_t detexhipHalfFloatToUNorm8(uint16_t half_bits);
 
+/* The reference's decoders differ from the BPTC specification in two places, and this library
+ * reproduces both by default so that its output is the reference's, bit for bit:
+ *   DETEXHIP_QUIRK_BC7_MODE6_PBIT      BC7 mode 6: the second endpoint's P-bit (block bit 64) reads 0 (decompress-bptc.c:142-146)
+ *   DETEXHIP_QUIRK_BC6H_MODE12_BIT63   BC6H mode 12: block bit 63 (b0[11]) reads 0 in the reference build (decompress-bptc-float.c:462,
+ *                                      an undefined shift in bits.h:29-31 as gcc >= -O2 compiles it)
+ * detexhipSetQuirks(mask) chooses, for the calling thread, which of them stay on; a cleared bit gives the specification's
+ * result for that case (what hardware decoders and other software decoders produce).  Default: DETEXHIP_QUIRKS_REFERENCE, or
+ * the value of DETEXHIP_QUIRKS in the environment (read when the thread first decodes).  Applies to every entry point. */
+enum { DETEXHIP_QUIRK_BC7_MODE6_PBIT = 1, DETEXHIP_QUIRK_BC6H_MODE12_BIT63 = 2, DETEXHIP_QUIRKS_REFERENCE = 3 };
+DETEXHIP_API void detexhipSetQuirks(uint32_t quirks);
+DETEXHIP_API uint32_t detexhipGetQuirks(void);
+
 /* Kernel-variant selection for A/B measurements.  The product library has ONE kernel per
  * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab,
  * -DDETEXHIP_AB_VARIANTS; detex_amd/csrc/ab/ab_dispatch.h lists them).  Unknown values fall back to 0.

@@ -17,6 +17,12 @@
  */
 #include <string.h>
 #include "detex_oracle.h"
+
+/* Reference quirks A-2 / A-3 are reproduced by default; orc_set_quirks(0) gives the
+ * specification's behaviour instead -- the checker for libdetexhip's detexhipSetQuirks().  Not thread-safe: tests set it
+ * around single-threaded calls only. */
+static unsigned orc_quirks = ORC_QUIRK_BC7_MODE6_PBIT | ORC_QUIRK_BC6H_MODE12_BIT63;
+void orc_set_quirks(unsigned mask) { orc_quirks = mask; }
 #include "bptc_partitions.inc"
 
 /* flag / mask values: detex.h:383-411 */
@@ -485,7 +491,7 @@ static int decode_bptc(const uint8_t *in, uint32_t mode_mask, uint32_t flags, ui
 		for (int e = 0; e < 2 * ns; e++) {
 			/* QUIRK A-2: in mode 6 the reference takes both P-bits from (data0 >> 63), so the
 			 * second one (block bit 64) reads as 0 (decompress-bptc.c:142-146). */
-			int p = (mode == 6 && e == 1) ? 0 : (int)bit_at(&br, br.pos + e);
+			int p = (mode == 6 && e == 1 && (orc_quirks & ORC_QUIRK_BC7_MODE6_PBIT)) ? 0 : (int)bit_at(&br, br.pos + e);
 			for (int c = 0; c < 4; c++) ep[e][c] = (ep[e][c] << 1) | p;
 		}
 		br.pos += 2 * ns;
@@ -596,7 +602,7 @@ static void bc6h_scatter(const uint8_t *in, int mode, int mode_bits, int comp[3]
 			uint32_t bit = bit_at(&br, br.pos);
 			/* QUIRK A-3: mode 12 loses b0[11] = block bit 63 (decompress-bptc-float.c:462,
 			 * UB shift in bits.h:29-31 as compiled by gcc >= -O2). */
-			if (mode == 12 && br.pos == 63) bit = 0;
+			if (mode == 12 && br.pos == 63 && (orc_quirks & ORC_QUIRK_BC6H_MODE12_BIT63)) bit = 0;
 			br.pos++;
 			comp[c][e] |= (int)(bit << k);
 			if (k == a) break;

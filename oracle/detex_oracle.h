@@ -32,6 +32,10 @@ enum {
 };
 
 /* compressed block size (8/16) and native pixel size in bytes for a format index; 0 if invalid */
+/* quirk switch: bit 0 = A-2 (BC7 mode 6 second P-bit reads 0), bit 1 = A-3 (BC6H mode 12 drops block bit 63); default both */
+#define ORC_QUIRK_BC7_MODE6_PBIT 1u
+#define ORC_QUIRK_BC6H_MODE12_BIT63 2u
+void orc_set_quirks(unsigned mask);
 int orc_block_bytes(int fmt);
 int orc_pixel_bytes(int fmt);
 

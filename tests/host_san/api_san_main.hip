@@ -1,0 +1,121 @@
+// tests/host_san/api_san_main.hip -- TEST-ONLY: the host side of libdetexhip (argument validation, error convention, the
+// conversion-table builder) compiled with AddressSanitizer + UndefinedBehaviorSanitizer (hipcc -fsanitize=address,undefined
+// -fno-gpu-sanitize: host code only) and called with hostile arguments.  Every call below must be REFUSED with an error
+// message and must not touch memory it was not given; a sanitizer report aborts with a non-zero exit code.  Runs without a GPU
+// (calls that pass validation then fail with "no usable HIP device"), and with one.  Not part of the product.
+#include "../../detex_amd/csrc/detexhip.hip"
+
+#include <vector>
+
+static int g_failures = 0;
+#define REFUSED(expr)                                                                                   \
+	do {                                                                                                \
+		detexSetErrorMessage("(none)");                                                                 \
+		const bool accepted = (expr);                                                                   \
+		const char *m = detexGetErrorMessage();                                                         \
+		if (accepted || !m || !strcmp(m, "(none)")) { printf("NOT REFUSED: %s (message: %s)\n", #expr, m ? m : "NULL"); g_failures++; } \
+	} while (0)
+
+int main() {
+	std::vector<uint8_t> blocks(4096, 0x5A), pixels(1 << 16, 0);
+	uint8_t *in = blocks.data(), *out = pixels.data();
+	const uint32_t BC1 = DETEX_TEXTURE_FORMAT_BC1, RGBA8 = DETEX_PIXEL_FORMAT_RGBA8;
+	// formats and pixel formats outside the path
+	REFUSED(detexDecompressBlock(in, 0x00000320u, DETEX_MODE_MASK_ALL, 0, out, RGBA8));
+	REFUSED(detexDecompressBlock(in, 0xFF000320u, DETEX_MODE_MASK_ALL, 0, out, RGBA8));
+	REFUSED(detexDecompressBlock(in, 0x14000320u, DETEX_MODE_MASK_ALL, 0, out, RGBA8));
+	REFUSED(detexDecompressBlock(in, BC1, DETEX_MODE_MASK_ALL, 0, out, 0x2721u));
+	REFUSED(detexDecompressBlock(in, DETEX_TEXTURE_FORMAT_BPTC_SIGNED_FLOAT, DETEX_MODE_MASK_ALL, 0, out, RGBA8));
+	// texture drivers: negative and inconsistent geometry, unknown formats (image zeroed, false)
+	detexTexture t = { BC1, in, -4, 4, 1, 1 };
+	REFUSED(detexDecompressTextureLinear(&t, out, RGBA8));
+	t = detexTexture{ BC1, in, 4, 4, -1, 1 };
+	REFUSED(detexDecompressTextureTiled(&t, out, RGBA8));
+	t = detexTexture{ 0x15000320u, in, 8, 8, 2, 2 };
+	memset(out, 0xEE, 256);
+	REFUSED(detexDecompressTextureLinear(&t, out, RGBA8));
+	for (int k = 0; k < 8 * 8 * 4; k++) if (out[k] != 0) { printf("unknown format: image not zeroed\n"); g_failures++; break; }
+	if (out[8 * 8 * 4] != 0) { printf("unknown format: wrote past the image\n"); g_failures++; }
+	t = detexTexture{ DETEX_PIXEL_FORMAT_RGBA8, in, 4, 4, 1, 1 };		// uncompressed: only the identity edge is on the path
+	REFUSED(detexDecompressTextureLinear(&t, out, 0x0101u));
+	REFUSED(detexDecompressTextureTiled(&t, out, RGBA8));
+	if (!detexDecompressTextureLinear(&t, out, RGBA8) || memcmp(out, in, 64) != 0) { printf("identity copy failed\n"); g_failures++; }
+	// device tier
+	REFUSED(detexhipDecompressTextureLinearDevice(0x99000000u, in, 4, 4, 1, 1, out, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, 4, 4, 1, 1, out, 16, 0x1234u, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, -4, 4, 1, 1, out, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, 4, 4, 1, 1, out, 15, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, 8, 4, 2, 1, out, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in + 4, 4, 4, 1, 1, out, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, 4, 4, 1, 1, out + 2, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureLinearDevice(BC1, in, 4, 4, 0x7FFFFFFF, 0x7FFFFFFF, out, 16, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureTiledDevice(BC1, in, -1, 1, out, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureTiledDevice(BC1, in, 1, 1, out + 4, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressTextureTiledDevice(BC1, in, 1, 1, out, 0x4444u, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressBlocksDevice(0, in, 1, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressBlocksDevice(BC1, in + 1, 1, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressBlocksDevice(BC1, in, (size_t)1 << 40, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
+	// mip levels
+	detexhipLevel lv[17];
+	for (auto &l : lv) l = detexhipLevel{ in, out, 16, 4, 4, 1, 1 };
+	REFUSED(detexhipDecompressLevelsLinearDevice(BC1, lv, -1, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressLevelsLinearDevice(BC1, lv, 17, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressLevelsLinearDevice(BC1, nullptr, 2, RGBA8, nullptr, nullptr) == 0);
+	REFUSED(detexhipDecompressLevelsLinearDevice(0x77000000u, lv, 1, RGBA8, nullptr, nullptr) == 0);
+	lv[0].pitch_bytes = 8;
+	REFUSED(detexhipDecompressLevelsLinearDevice(BC1, lv, 1, RGBA8, nullptr, nullptr) == 0);
+	lv[0].pitch_bytes = 16; lv[0].width = -1;
+	REFUSED(detexhipDecompressLevelsLinearDevice(BC1, lv, 1, RGBA8, nullptr, nullptr) == 0);
+	// histogram
+	uint32_t hist[16];
+	REFUSED(detexhipModeHistogramDevice(0x55000000u, in, 1, hist, nullptr) == 0);
+	REFUSED(detexhipModeHistogramDevice(BC1, in, 1, nullptr, nullptr) == 0);
+	REFUSED(detexhipModeHistogramDevice(BC1, in + 3, 1, hist, nullptr) == 0);
+	REFUSED(detexhipModeHistogramAccumulateDevice(BC1, in, (size_t)1 << 33, hist, nullptr) == 0);
+	REFUSED(detexhipModeHistogram(0, in, 1, hist));
+	// sharding and the multi-device entries
+	int r0 = -7, r1 = -7;
+	REFUSED(detexhipShardRows(8, 0, 0, &r0, &r1) == 0);
+	REFUSED(detexhipShardRows(8, 4, 4, &r0, &r1) == 0);
+	REFUSED(detexhipShardRows(-1, 4, 0, &r0, &r1) == 0);
+	REFUSED(detexhipShardRows(8, 4, 0, nullptr, &r1) == 0);
+	if (detexhipShardRows(0x7FFFFFFF, 64, 63, &r0, &r1) != 0 || r1 != 0x7FFFFFFF || r0 < 0 || r0 > r1) { printf("detexhipShardRows overflows\n"); g_failures++; }
+	detexhipShard sh[2] = { { 0, nullptr, out, 0, 0, 0.f, 0 }, { 0, nullptr, out, 0, 0, 0.f, 0 } };
+	float ms = 0;
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, nullptr, 2, -1, nullptr, &ms, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, sh, 0, -1, nullptr, &ms, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, sh, 65, -1, nullptr, &ms, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, sh, 2, 0, nullptr, &ms, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 4, RGBA8, sh, 2, -1, nullptr, &ms, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDevice(0, in, 8, 8, 2, 2, 0, RGBA8, sh, 2, -1, nullptr, &ms, &ms) == 0);
+	int devs[2] = { 0, 0 }, invalid = 0;
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, in, 8, 8, 2, 2, out, 0, RGBA8, nullptr, 2, &invalid, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, nullptr, 8, 8, 2, 2, out, 0, RGBA8, devs, 2, &invalid, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, in, 8, 8, 2, 2, nullptr, 0, RGBA8, devs, 2, &invalid, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, in, 8, 8, 2, 2, out, 8, RGBA8, devs, 2, &invalid, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, in, 8, 8, 2, 2, out, 0, 0x7777u, devs, 2, &invalid, &ms) == 0);
+	REFUSED(detexhipDecompressTextureLinearMultiDeviceHost(BC1, in, 8, -8, 2, 2, out, 0, RGBA8, devs, 2, &invalid, &ms) == 0);
+	// device selection, knobs
+	REFUSED(detexhipSetDevice(-1) == 0);
+	REFUSED(detexhipSetDevice(1 << 20) == 0);
+	detexhipSetKernelVariant(99); if (detexhipGetKernelVariant() != 0) { printf("variant 99 accepted\n"); g_failures++; }
+	detexhipSetQuirks(0xFFFFFFFFu); if (detexhipGetQuirks() != DETEXHIP_QUIRKS_REFERENCE) { printf("quirk mask not clipped\n"); g_failures++; }
+	detexhipSetQuirks(0); if (detexhipGetQuirks() != 0) { printf("quirk mask not stored\n"); g_failures++; }
+	if (detexhipKernelName(0) != nullptr || detexhipKernelName(0xFF000000u) != nullptr || detexhipKernelName(BC1) == nullptr) { printf("detexhipKernelName\n"); g_failures++; }
+	// the conversion-table builder over every half bit pattern (float -> int conversions under UBSan), monotone on [0, 1]
+	unsigned prev = 0;
+	for (uint32_t h = 0; h < 65536u; h++) {
+		const unsigned v = detexhipHalfFloatToUNorm8((uint16_t)h);
+		if (h <= 0x3C00u) { if (v < prev) { printf("half table not monotone at 0x%04X\n", h); g_failures++; break; } prev = v; }
+		if (h > 0x8000u && h < 0xFC00u && v != 0) { printf("negative half 0x%04X -> %u\n", h, v); g_failures++; break; }
+	}
+	// the error convention with long and odd messages, and release without a context
+	std::vector<char> big(100000, 'x'); big.back() = 0;
+	detexSetErrorMessage("%s|%s", big.data(), big.data());
+	if (!detexGetErrorMessage() || strlen(detexGetErrorMessage()) != 2 * (big.size() - 1) + 1) { printf("long error message truncated\n"); g_failures++; }
+	detexSetErrorMessage("%%|%c|%5d|%-8s|", 'a', -3, "b");
+	detexhipReleaseThreadResources();
+	detexhipReleaseThreadResources();
+	printf("api_san: %d problems, no sanitizer report\n", g_failures);
+	return g_failures ? 2 : 0;
+}

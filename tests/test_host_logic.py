@@ -129,6 +129,29 @@ def test_alternative_decoders_under_emulation(alt, name, emul, oracle, forced_ve
         assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
 
 
+@pytest.mark.parametrize("index,name,spec_flag,quirk", [(11, "BPTC", 1 << 30, 1), (111, "BPTC", 1 << 30, 1), (9, "BPTC_FLOAT", 1 << 31, 2), (10, "BPTC_SIGNED_FLOAT", 1 << 31, 2),
+                                                         (109, "BPTC_FLOAT", 1 << 31, 2), (110, "BPTC_SIGNED_FLOAT", 1 << 31, 2)])
+def test_spec_switches_under_emulation(index, name, spec_flag, quirk, emul, oracle, forced_vectors):
+    """the decoders' spec-conformance flags (bptc_common.h: kFlagSpec..., set by detexhipSetQuirks) against the checker with the
+    corresponding quirk off (tests/test_quirks.py pins that switch)"""
+    import types
+    fmt = F.BY_NAME[name]
+    blocks = np.concatenate([forced_vectors[name + "/in"], ol.stream_u(fmt, 1 << 14, seed=0x5EC + index).reshape(-1, fmt.block_bytes)])
+    shim = types.SimpleNamespace(index=index, block_bytes=fmt.block_bytes, pixel_bytes=fmt.pixel_bytes)
+    oracle.lib.orc_set_quirks.argtypes = [ctypes.c_uint]
+    try:
+        oracle.lib.orc_set_quirks(3 & ~quirk)
+        ok_o, out_o = oracle.blocks(fmt, blocks)
+        for checked in (1, 0):
+            ok_e, out_e = emul(shim, blocks, flags=spec_flag, checked=checked)
+            assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
+        oracle.lib.orc_set_quirks(3)
+        ok_q, out_q = oracle.blocks(fmt, blocks)
+        assert (out_q != out_o).any(), "the forced vectors contain blocks the quirk changes"
+    finally:
+        oracle.lib.orc_set_quirks(3)
+
+
 def test_signed_bc6h_extreme_magnitudes_under_emulation(emul, oracle):
     """mode-13 blocks whose interpolated value reaches -32768 (sign-magnitude half 0xFC00): the packed 16-bit
     finish of the signed BC6H kernel must treat |v| = 0x8000 as unsigned (tests/golden/bc6h_signed_extreme_blocks.npy:
