@@ -225,8 +225,7 @@ template <int CLASS, int DWORDS> hipError_t launch_histogram(const void *blocks,
 	const unsigned max_grid = DWORDS == 2 ? 256u : 192u;
 	const size_t tiles = (n + kHistogramLanes - 1) / kHistogramLanes;
 	const unsigned grid = (unsigned)(tiles < max_grid ? tiles : max_grid);
-	if (zero_first) hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS, true>), dim3(grid), dim3(kHistogramLanes), 0, stream, static_cast<const uint32_t *>(blocks), (uint32_t)n, hist);
-	else hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS, false>), dim3(grid), dim3(kHistogramLanes), 0, stream, static_cast<const uint32_t *>(blocks), (uint32_t)n, hist);
+	hipLaunchKernelGGL((mode_histogram<CLASS, DWORDS>), dim3(grid), dim3(kHistogramLanes), 0, stream, static_cast<const uint32_t *>(blocks), (uint32_t)n, hist);
 	return hipGetLastError();
 }
 

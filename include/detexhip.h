@@ -164,7 +164,8 @@ DETEXHIP_API bool detexhipHostDecompressTextureTiled(const detexTexture *texture
 DETEXHIP_API int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
 	uint32_t *d_hist, void *stream);
 /* The same count ADDED to d_hist (not zeroed): one histogram over several textures or the levels of a mip chain; a single
- * kernel launch, where the call above is a 64-byte memset plus the kernel. */
+ * kernel launch, where the call above is a 64-byte memset plus the kernel.  Every bin must stay below 2^32 over the whole
+ * accumulation (bins are added in pairs by 64-bit atomics: past the limit an even bin carries into its neighbour). */
 DETEXHIP_API int detexhipModeHistogramAccumulateDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
 	uint32_t *d_hist, void *stream);
 DETEXHIP_API bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,

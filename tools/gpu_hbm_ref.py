@@ -30,6 +30,15 @@ for mib in (256, 1024):
     for nt in (True, False):
         gbps, us = hbmref.copy_GBps(mib << 20, nt, 30)
         emit({"op": "copy", "MiB": mib, "nontemporal": nt, "us": round(us, 1), "TBps_read_plus_written": round(gbps / 1e3, 3)})
+# how many 16-byte stores a wave issues: 1 (a workgroup writes 4 KiB -- the shape of torch's fill kernel) .. 8
+for mib in (256, 1024):
+    for rows in (1, 2, 4, 8):
+        for nt in (True, False, 2):
+            gbps, us = hbmref.fill_rows_GBps(mib << 20, rows, nt, 30)
+            emit({"op": "fill_rows", "MiB": mib, "stores_per_lane": rows, "nontemporal": bool(nt), "wave_contiguous": nt == 2, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
+for rows in (1, 4):
+    gbps, us = hbmref.fill_rows_GBps(1 << 30, rows, 3, 30)
+    emit({"op": "fill_rows_one_wave_workgroups", "MiB": 1024, "stores_per_lane": rows, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
 # the fill in the decode kernels' image layout, and through stores that are only dword-aligned
 for (wbytes, h) in ((32768, 8192), (65536, 8192), (65536, 16384)):
     for pat in (0, 2):

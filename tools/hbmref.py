@@ -18,6 +18,7 @@ def load():
         lib.hbmref_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         lib.hbmref_fill_unaligned.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
         lib.hbmref_fill_image.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+        lib.hbmref_fill_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -91,5 +92,18 @@ def fill_unaligned_GBps(nbytes, offset, launches=30):
     def step():
         if lib.hbmref_fill_unaligned(buf.data_ptr() + offset, nbytes, 7, st) != 0:
             raise RuntimeError("hbmref_fill_unaligned failed")
+    us = time_us(step, launches)
+    return nbytes / (us * 1e-6) / 1e9, us
+
+
+def fill_rows_GBps(nbytes, rows, nontemporal, launches=30):
+    import torch
+    lib = load()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        if lib.hbmref_fill_rows(buf.data_ptr(), nbytes, rows, int(nontemporal), 7, st) != 0:
+            raise RuntimeError("hbmref_fill_rows failed")
     us = time_us(step, launches)
     return nbytes / (us * 1e-6) / 1e9, us

@@ -63,6 +63,32 @@ template <int PATTERN> __global__ __launch_bounds__(256) void fill_image_kernel(
 		__builtin_nontemporal_store(make_vector<PATTERN>(blockIdx.x * 1024u + r * 256u + threadIdx.x, seed), p + (uint64_t)r * pitch_vectors);
 }
 
+// the linear fill with ROWS vectors per lane (ROWS = 1: a workgroup writes 4 KiB and every wave issues ONE store, the shape of
+// torch's fill kernel)
+// WAVE_CONTIGUOUS: a wave's ROWS stores cover ROWS consecutive KiB (instead of one KiB in each of ROWS 4 KiB pieces)
+template <int ROWS, bool NT, bool WAVE_CONTIGUOUS = false> __global__ __launch_bounds__(256) void fill_rows_kernel(v4 *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint64_t base = (uint64_t)blockIdx.x * (256u * ROWS);
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) {
+		const uint64_t i = WAVE_CONTIGUOUS ? base + ((threadIdx.x >> 6) * ROWS + r) * 64u + (threadIdx.x & 63u) : base + (uint64_t)r * 256u + threadIdx.x;
+		if (i < n_vectors) {
+			const v4 v = make_vector<2>((uint32_t)i, seed);
+			if (NT) __builtin_nontemporal_store(v, dst + i);
+			else dst[i] = v;
+		}
+	}
+}
+
+// one-wave workgroups: 64 lanes x ROWS stores (is it the stores per wave or the bytes per workgroup that decide the rate?)
+template <int ROWS> __global__ __launch_bounds__(64) void fill_wave_kernel(v4 *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint64_t base = (uint64_t)blockIdx.x * (64u * ROWS);
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) {
+		const uint64_t i = base + (uint64_t)r * 64u + threadIdx.x;
+		if (i < n_vectors) __builtin_nontemporal_store(make_vector<2>((uint32_t)i, seed), dst + i);
+	}
+}
+
 template <bool NT> __global__ __launch_bounds__(256) void copy_kernel(v4 *__restrict__ dst, const v4 *__restrict__ src, uint64_t n_vectors) {
 	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
 	v4 v[4];
@@ -119,5 +145,27 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill_image(void *ds
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (pattern == 0) hipLaunchKernelGGL((fill_image_kernel<0>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
 	else hipLaunchKernelGGL((fill_image_kernel<2>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_rows(void *dst, size_t bytes, int rows, int nontemporal, uint32_t seed, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+	const dim3 block(256);
+#define ROWS_CASE(R) case R: { const dim3 grid((unsigned)((n + 256u * R - 1u) / (256u * R))); \
+	if (nontemporal == 2) hipLaunchKernelGGL((fill_rows_kernel<R, true, true>), grid, block, 0, s, d, n, seed); \
+	else if (nontemporal) hipLaunchKernelGGL((fill_rows_kernel<R, true>), grid, block, 0, s, d, n, seed); \
+	else hipLaunchKernelGGL((fill_rows_kernel<R, false>), grid, block, 0, s, d, n, seed); break; }
+	if (nontemporal == 3) {		// one-wave workgroups, non-temporal
+		const dim3 grid((unsigned)((n + 64u * rows - 1u) / (64u * rows)));
+		if (rows == 4) hipLaunchKernelGGL((fill_wave_kernel<4>), grid, dim3(64), 0, s, d, n, seed);
+		else if (rows == 1) hipLaunchKernelGGL((fill_wave_kernel<1>), grid, dim3(64), 0, s, d, n, seed);
+		else return 1;
+		return hipGetLastError() == hipSuccess ? 0 : 1;
+	}
+	switch (rows) { ROWS_CASE(1) ROWS_CASE(2) ROWS_CASE(4) ROWS_CASE(8) default: return 1; }	// nontemporal = 2: non-temporal, wave-contiguous
+#undef ROWS_CASE
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
