@@ -36,6 +36,9 @@ template <class Dec> static void run(const uint8_t *in, long n, uint32_t mode_ma
 	}
 }
 
+// what the other lanes of the emulated wave answer to a ballot (0 = nothing, ~0 = yes to everything: hip_host_shim.h)
+extern "C" void emul_set_other_lanes_vote(unsigned long long v) { emul_other_lanes_vote = v; }
+
 extern "C" int emul_decode_blocks(int fmt, const uint8_t *in, long n, uint32_t mode_mask, uint32_t flags, int checked, uint8_t *out, uint8_t *ok) {
 	switch (fmt) {
 	case 1: run<DecBC1>(in, n, mode_mask, flags, checked, out, ok); break;

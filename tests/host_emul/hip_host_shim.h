@@ -43,5 +43,9 @@ static inline int32_t __mul24(int32_t a, int32_t b) {
 	const int32_t sa = (int32_t)((uint32_t)a << 8) >> 8, sb = (int32_t)((uint32_t)b << 8) >> 8;
 	return (int32_t)((int64_t)sa * sb);
 }
-// wave-uniform votes: the emulation runs one "lane" at a time, so a ballot is just the predicate
-static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }
+// wave-uniform votes: the emulation runs one "lane" at a time, so a ballot is just the predicate -- OR the vote of the
+// imaginary other lanes of the wave (emul_other_lanes_vote, set by the test): with it set every "does any lane of the wave ...?"
+// answers yes, i.e. each block is decoded the way it is inside a maximally mixed wave (BC7: three subsets, alpha, two index
+// streams expanded for every block whatever its own mode)
+static unsigned long long emul_other_lanes_vote = 0ull;
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return (p ? 1ull : 0ull) | emul_other_lanes_vote; }

@@ -92,7 +92,11 @@ def emul():
     u8p = ctypes.POINTER(ctypes.c_uint8)
     lib.emul_decode_blocks.argtypes = [ctypes.c_int, u8p, ctypes.c_long, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, u8p, u8p]
 
-    def run(fmt, blocks, mask=0xFFFFFFFF, flags=0, checked=1):
+    lib.emul_set_other_lanes_vote.argtypes = [ctypes.c_ulonglong]
+
+    def run(fmt, blocks, mask=0xFFFFFFFF, flags=0, checked=1, mixed_wave=False):
+        """mixed_wave: every wave-uniform vote answers yes -- each block decoded as inside a wave that holds every kind of block"""
+        lib.emul_set_other_lanes_vote(0xFFFFFFFFFFFFFFFE if mixed_wave else 0)
         blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1)
         n = blocks.size // fmt.block_bytes
         out = np.zeros((n, 16 * fmt.pixel_bytes), np.uint8)
@@ -111,9 +115,10 @@ def test_device_logic_under_emulation(fmt, emul, oracle, forced_vectors):
         ok_o, out_o = oracle.blocks(fmt, blocks, mask, flags)
         assert np.array_equal(ok_e, ok_o), (fmt.name, hex(mask), flags)
         assert np.array_equal(out_e, out_o), (fmt.name, hex(mask), flags)
-    ok_e, out_e = emul(fmt, blocks, checked=0)          # the texture-driver instantiation (mask ALL, flags 0 folded away)
     ok_o, out_o = oracle.blocks(fmt, blocks)
-    assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o)
+    for mixed in (False, True):                         # alone in its wave / inside a wave that holds every kind of block
+        ok_e, out_e = emul(fmt, blocks, checked=0, mixed_wave=mixed)          # the texture-driver instantiation (mask ALL, flags 0 folded away)
+        assert np.array_equal(ok_e, ok_o) and np.array_equal(out_e, out_o), (fmt.name, mixed)
 
 
 @pytest.mark.parametrize("alt,name", [(109, "BPTC_FLOAT"), (110, "BPTC_SIGNED_FLOAT"), (111, "BPTC")])
