@@ -512,6 +512,9 @@ def main():
             table["%s/%s" % (name, kind) + ("/tiled" if layout == "tiled" else "")] = row
             del j
         torch.cuda.empty_cache()
+        if result["roofline"].get("ref_copy_GBps"):     # a mixed read + write stream: beside the 8 TB/s fraction, the fraction of the copy measured in this process
+            for row in table.values():
+                row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
         result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran)",
                                 "seconds": round(time.perf_counter() - t_start, 2), "formats": table}
         # the headline format beyond the Infinity Cache: 16384^2 = 1 GiB of pixels
