@@ -389,6 +389,28 @@ def test_wide_non_power_of_two_band_vs_oracle(name, torch_cuda, oracle):
     assert np.array_equal(got_t.cpu().numpy(), want_t), name
 
 
+@pytest.mark.parametrize("name", ["BC1", "BPTC", "BPTC_FLOAT", "RGTC2", "EAC_R11"])
+def test_block_grid_smaller_or_larger_than_the_image(name, torch_cuda, oracle):
+    """texture.c:116-136 with a block grid that does not match the image: a grid that covers only part of the image leaves the
+    other pixels untouched (canary), a grid that is larger has its surplus blocks dropped -- through the staged kernel (dword-aligned
+    rows), for widths on both sides of a 256-block tile"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    px = fmt.pixel_bytes
+    for (W, H, wb, hb) in ((1000, 52, 200, 10), (1000, 52, 260, 15), (2052, 20, 513, 5), (2052, 20, 300, 7), (64, 64, 20, 3), (36, 12, 9, 5)):
+        data = ol.stream_u(fmt, wb * hb, seed=0x6A1D + wb)
+        want = np.full(W * H * px, 0xA5, np.uint8)
+        ok_o = oracle.lib.orc_decompress_linear(fmt.index, ol._ptr(data), W, H, wb, hb, ol._ptr(want))
+        canvas = torch.full((W * H * px + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        binding.decompress_linear_device(fmt, _dev(torch, data), W, H, out=canvas, status=status, width_in_blocks=wb, height_in_blocks=hb)
+        torch.cuda.synchronize()
+        got = canvas.cpu().numpy()
+        assert np.array_equal(got[:W * H * px], want), (name, W, H, wb, hb, _first_diff(got[:W * H * px], want, px))
+        assert (got[W * H * px:] == 0xA5).all() and bool(status.item() == 0) == bool(ok_o), (name, W, H, wb, hb)
+
+
 def test_clipped_large_digests(torch_cuda, golden_json, oracle):
     """Large textures whose width / height are not multiples of four (texture.c:116-120, 132-136) against digests of the
     compiled reference's output: the interior goes through the throughput kernel (rows 16-byte aligned, or only dword-aligned
