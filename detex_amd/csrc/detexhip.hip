@@ -70,10 +70,11 @@ namespace {
 struct Geometry {
 	const void *blocks; void *pixels; uint32_t wb, hb, width, height; uint64_t pitch;
 	uint32_t *status; hipStream_t stream; int variant; int epi; uint32_t decode_flags;
+	int resident;		// workgroups per CU the linear kernel of this format runs best with (FormatEntry::resident; 0 = no cap)
 };
 struct BatchArgs {
 	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
-	hipStream_t stream; bool checked; int epi;
+	hipStream_t stream; bool checked; int epi; int resident;
 };
 
 // Calls fn(std::integral_constant<int, EPI>) for the epilogue `epi` if the decoder's native pixel class can feed it
@@ -118,6 +119,22 @@ template <class Dec, int EPI> bool fast_geometry(const Geometry &g, bool *sector
 	return (g.width & 3u) == 0 && (g.height & 3u) == 0 && g.wb * 4u == g.width && g.hb * 4u == g.height && (place % align) == 0;
 }
 
+// Dynamic LDS to request at launch so that at most `target` workgroups of `kernel` are resident per CU (0 = no cap).  The
+// linear kernels are store-bound, and the write path runs better with FEWER concurrent store streams than the eight workgroups
+// per CU the registers allow (BC1 8192^2 42.5 -> 41.5 us at three to five per CU, BC6H on coherent content
+// 92.6 -> 84.7 at three); unused LDS is the one launch-time handle on residency.  160 KiB per CU; the request is rounded down to
+// 2 KiB so that `target` workgroups fit whatever the allocation granule, and target + 1 never do (true for 3 <= target <= 7).
+template <auto Kernel> unsigned occupancy_cap_lds(int target) {		// (one cached attribute query per kernel instantiation)
+	if (target < 3 || target > 7) return 0u;
+	static const size_t static_lds = [] {
+		hipFuncAttributes a{};
+		return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(Kernel)) == hipSuccess ? a.sharedSizeBytes : (size_t)0;
+	}();
+	const size_t per_workgroup = ((size_t)163840 / (size_t)target) & ~(size_t)2047;
+	return per_workgroup > static_lds ? (unsigned)(per_workgroup - static_lds) : 0u;
+}
+constexpr int workgroups_per_cu(int per_format) { return Tune::kWorkgroupsPerCu >= 0 ? Tune::kWorkgroupsPerCu : per_format; }
+
 template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 	const uint32_t n = g.wb * g.hb, tiles = (n + 255u) / 256u;
 	uint8_t *px = static_cast<uint8_t *>(g.pixels);
@@ -134,13 +151,16 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 		constexpr int kRow = EpilogueOf<Dec, EPI>::kRowDwords, kGroup = kRow * LaneBlocks<Dec>::value <= 4 ? LaneBlocks<Dec>::value : 1;
 		if constexpr (kGroup > 1) {
 			if (g.wb % kGroup == 0 && (reinterpret_cast<uintptr_t>(px) | g.pitch) % (4u * kRow * kGroup) == 0) {
-				hipLaunchKernelGGL((decode_linear_grouped<Dec, EPI, true, kGroup>), dim3((n / kGroup + 255u) / 256u), dim3(256), 0, g.stream,
+				constexpr auto kernel = &decode_linear_grouped<Dec, EPI, true, kGroup>;
+				hipLaunchKernelGGL(kernel, dim3((n / kGroup + 255u) / 256u), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream,
 					g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
 				return hipGetLastError();
 			}
 		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
-		hipLaunchKernelGGL((decode_linear<Dec, EPI, true>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
+		constexpr auto kernel = &decode_linear<Dec, EPI, true>;
+		hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch,
+			g.status, g.decode_flags);
 		return hipGetLastError();
 	}
 	// Everything else whose rows are dword-aligned and a whole number of dwords long -- clipped sizes (texture.c:116-120,
@@ -150,8 +170,9 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 	const size_t row_bytes = (size_t)g.width * (EpilogueOf<Dec, EPI>::kRowDwords);		// width pixels * (4 * ROW / 4) bytes
 	if (((reinterpret_cast<uintptr_t>(px) | (uintptr_t)g.pitch | row_bytes) & 3u) == 0 && row_bytes <= 0xFFFFFFFFull) {
 		const uint32_t tiles_per_row = (g.wb + 255u) / 256u;
-		hipLaunchKernelGGL((decode_linear_staged<Plain, EPI>), dim3(tiles_per_row * g.hb), dim3(256), 0, g.stream, g.blocks, px, g.wb, (uint32_t)row_bytes,
-			g.height, g.pitch, g.status, tiles_per_row, g.decode_flags);
+		constexpr auto kernel = &decode_linear_staged<Plain, EPI>;
+		hipLaunchKernelGGL(kernel, dim3(tiles_per_row * g.hb), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb,
+			(uint32_t)row_bytes, g.height, g.pitch, g.status, tiles_per_row, g.decode_flags);
 	} else {
 		hipLaunchKernelGGL((decode_linear_clipped<Plain, EPI>), dim3(tiles), dim3(256), 0, g.stream, g.blocks, px, g.wb, n, g.width, g.height, g.pitch,
 			g.status, g.decode_flags);
@@ -171,7 +192,8 @@ template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 		hipLaunchKernelGGL((decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n,
 			a.mode_mask, a.flags, a.ok, a.status);
 	} else {
-		hipLaunchKernelGGL((decode_blocks<Dec, EPI, false>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
+		constexpr auto kernel = &decode_blocks<Dec, EPI, false>;		// the block-major texture driver: store-bound like the linear kernel
+		hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(a.resident)), a.stream, a.blocks, px, (uint32_t)a.n, a.mode_mask,
 			a.flags, a.ok, a.status);
 	}
 	return hipGetLastError();
@@ -238,22 +260,33 @@ struct FormatEntry {
 	hipError_t (*levels)(LevelsArgs &);
 	hipError_t (*histogram)(const void *, size_t, uint32_t *, hipStream_t, bool);
 	const char *kernel_name;
+	int resident;		// resident workgroups per CU of the linear kernels (occupancy_cap_lds); 0 = whatever fits
+	int resident_blocks;	// the same for the block-major texture driver
 };
 
-#define FMT(NAME, DEC, CLS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, &launch_levels<DEC>, \
-	&launch_histogram<CLS, DEC::kBlockBytes / 4>, "decode_linear<detexhip::" #DEC }
+#define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
+	&launch_levels<DEC>, &launch_histogram<CLS, DEC::kBlockBytes / 4>, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS }
 
+// Last column: resident workgroups per CU of the linear kernel (occupancy_cap_lds), from the sweep of round 3
+// (tools/gpu_wg_sweep.sh, profiles/r03/wg_sweep/; 8192^2, streams U / C, caps 3..7 against none).  The store-bound kernels with
+// 32-bit or wider pixels and little VALU work gain 1-2.6 % at four or five workgroups per CU (BC1 42.1 -> 41.9, BC1A on its fixture
+// 40.1 -> 39.3, BC3 47.5 -> 46.6, ETC1 42.8 -> 42.1); BC6H gains 11 % on coherent content (92.2 -> 82.0 us at five; its fixture
+// tiled, which is what encoder-made textures look like) at the price of 2.6 % on uniform-random blocks, where the kernel sits at the
+// board's power cap and needs every wave (85.2 -> 87.4) -- taken; signed BC6H has no fixture to show a gain and keeps all of them,
+// as do BC7, ETC2_EAC and the narrow RGTC1 formats, which lose with any cap; ETC2 / punchthrough gain 3-4 % on their fixtures at
+// five / six and nothing on random data.  The block-major driver (second number): the plain formats gain 1-2 % at five as well, ETC2
+// and BC6H lose (their staging already takes the LDS of several workgroups) and keep what fits.
 const FormatEntry kFormats[20] = {
-	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr },
-	FMT(BC1, DecBC1, kClassS3TC), FMT(BC1A, DecBC1A, kClassS3TC), FMT(BC2, DecBC2, kClassS3TCat8), FMT(BC3, DecBC3, kClassS3TCat8),
-	FMT(RGTC1, DecRGTC1, kClassNone), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone), FMT(RGTC2, DecRGTC2, kClassNone),
-	FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone),
-	FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat),
-	FMT(BPTC, DecBPTC, kClassBPTC),
-	FMT(ETC1, DecETC1, kClassETC1), FMT(ETC2, DecETC2, kClassETC2), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough, kClassETC2PT),
-	FMT(ETC2_EAC, DecETC2EAC, kClassETC2at8),
-	FMT(EAC_R11, DecEACR11, kClassNone), FMT(EAC_SIGNED_R11, DecEACSignedR11, kClassNone), FMT(EAC_RG11, DecEACRG11, kClassNone),
-	FMT(EAC_SIGNED_RG11, DecEACSignedRG11, kClassNone),
+	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 },
+	FMT(BC1, DecBC1, kClassS3TC, 5, 5), FMT(BC1A, DecBC1A, kClassS3TC, 5, 5), FMT(BC2, DecBC2, kClassS3TCat8, 5, 5), FMT(BC3, DecBC3, kClassS3TCat8, 5, 5),
+	FMT(RGTC1, DecRGTC1, kClassNone, 0, 0), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone, 0, 0), FMT(RGTC2, DecRGTC2, kClassNone, 6, 0),
+	FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone, 5, 5),
+	FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 0), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
+	FMT(BPTC, DecBPTC, kClassBPTC, 0, 0),
+	FMT(ETC1, DecETC1, kClassETC1, 5, 5), FMT(ETC2, DecETC2, kClassETC2, 5, 0), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough, kClassETC2PT, 6, 0),
+	FMT(ETC2_EAC, DecETC2EAC, kClassETC2at8, 0, 0),
+	FMT(EAC_R11, DecEACR11, kClassNone, 6, 0), FMT(EAC_SIGNED_R11, DecEACSignedR11, kClassNone, 6, 0), FMT(EAC_RG11, DecEACRG11, kClassNone, 5, 5),
+	FMT(EAC_SIGNED_RG11, DecEACSignedRG11, kClassNone, 5, 5),
 };
 
 const FormatEntry *lookup_format(uint32_t texture_format) {
@@ -637,7 +670,7 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 	const int epi = prepared_epilogue(texture_format, pixel_format);
 	if (epi == -2) return 1;
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
-		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epi, current_spec_flags() };
+		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), current_variant(), epi, current_spec_flags(), f->resident };
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -654,7 +687,7 @@ static int blocks_device(const char *who, uint32_t texture_format, const void *d
 		return 1;
 	}
 	// the reference's flags occupy bits 0-2 (detex.h:397-411); the spec switches ride in bits 30-31
-	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi };
+	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi, f->resident_blocks };
 	hipError_t e = f->blocks(a);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;

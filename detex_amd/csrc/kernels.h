@@ -218,6 +218,12 @@ template <int ROW> DH void store_row_dword_aligned(uint8_t *dst, const uint32_t 
 	}
 }
 
+// measurement builds only: a pause between a wave's row stores (Tune::kStoreSleep, 0 in the product)
+DH void store_pause() {
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (Tune::kStoreSleep > 0) __builtin_amdgcn_s_sleep(Tune::kStoreSleep);
+#endif
+}
 // raise the "some block was invalid" word without an atomic RMW storm (see header comment)
 DH void raise_status(bool bad, uint32_t *status) {
 	if (status == nullptr) return;
@@ -277,7 +283,9 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		if (ia < n_blocks) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a + (uint64_t)r * pitch));
+		store_pause();
 		if (ib < n_blocks) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b + (uint64_t)r * pitch));
+		store_pause();
 	}
 }
 
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 		if (stores_enabled(o)) {
 #pragma unroll
-			for (int r = 0; r < 4; r++) store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW);
+			for (int r = 0; r < 4; r++) { store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW); store_pause(); }
 		}
 		raise_status(!ok, status);
 	}

@@ -21,6 +21,11 @@ struct ProductTune {
 	static constexpr int kBc7Prio = 0;
 	// BC6H: the same priority staging
 	static constexpr int kBc6hPrio = 0;
+	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of detexhip.hip (kFormats), 0 = no cap, 3..7 = this
+	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
+	static constexpr int kWorkgroupsPerCu = -1;
+	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate?
+	static constexpr int kStoreSleep = 0;
 	// v_bitop3_b32 masks pinned into VGPRs (an SGPR source halves the issue rate of a full-rate VALU op)
 	static constexpr bool kMasksInVgprs = true;
 	// RGTC1: blocks per lane in the linear kernel

@@ -215,9 +215,22 @@ def stream_c(fmt, wb, hb):
 
 
 def make_stream(kind, fmt, wb, hb, seed=None):
-    """'U', 'M' or 'C' stream of wb x hb blocks (None if the kind does not exist for fmt)."""
+    """'U', 'M' or 'C' stream of wb x hb blocks (None if the kind does not exist for fmt).  Measurement-only kinds: 'Z' all-zero
+    blocks (every pixel decodes to zero for the formats it is used with), 'S' stream C with the fixture's blocks shuffled (same
+    blocks, same modes, no spatial coherence), 'K' one block of stream U repeated (constant image)."""
     import oracle_lib as ol
     if kind == "C":
         return stream_c(fmt, wb, hb)
+    if kind == "Z":
+        return np.zeros(wb * hb * fmt.block_bytes, np.uint8)
+    if kind == "S":
+        c = stream_c(fmt, wb, hb)
+        if c is None:
+            return None
+        b = c.reshape(-1, fmt.block_bytes)
+        return np.ascontiguousarray(b[np.random.default_rng(7).permutation(len(b))]).reshape(-1)
+    if kind == "K":
+        one = stream_m(fmt, ol.stream_u(fmt, 64, seed=seed)).reshape(-1, fmt.block_bytes)[5]
+        return np.ascontiguousarray(np.tile(one, wb * hb))
     data = ol.stream_u(fmt, wb * hb, seed=seed)
     return stream_m(fmt, data) if kind == "M" else data
