@@ -44,6 +44,11 @@ for (wbytes, h) in ((32768, 8192), (65536, 8192), (65536, 16384)):
     for pat in (0, 2):
         gbps, us = hbmref.fill_image_GBps(wbytes, h, pat, 30)
         emit({"op": "fill_image", "width_bytes": wbytes, "height": h, "MiB": wbytes * h >> 20, "pattern": pat, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
+# ... with the resident workgroups per CU capped (unused dynamic LDS), as the decode kernels' launches do
+for wg in (0, 7, 6, 5, 4, 3, 2):
+    for (wbytes, h) in ((32768, 8192), (65536, 16384)):
+        gbps, us = hbmref.fill_image_GBps(wbytes, h, 2, 40, 0, wg)
+        emit({"op": "fill_image_resident", "workgroups_per_cu": wg, "width_bytes": wbytes, "height": h, "MiB": wbytes * h >> 20, "us": round(us, 1), "TBps_written": round(gbps / 1e3, 3)})
 # ... with padded row pitches: what the memory system makes of an image whose rows are not a power of two apart
 for pad in (0, 64, 128, 256, 4096 + 64, 16, 32, 48):
     gbps, us = hbmref.fill_image_GBps(32768, 8192, 2, 60, 32768 + pad)

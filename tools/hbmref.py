@@ -68,10 +68,13 @@ def copy_GBps(nbytes, nontemporal=True, launches=30):
     return 2 * nbytes / (us * 1e-6) / 1e9, us
 
 
-def fill_image_GBps(width_bytes, height, pattern=2, launches=30, pitch_bytes=0):
-    """write-only fill in the decode kernels' image layout (four 4 KiB row pieces per workgroup); bytes written per second"""
+def fill_image_GBps(width_bytes, height, pattern=2, launches=30, pitch_bytes=0, workgroups_per_cu=0):
+    """write-only fill in the decode kernels' image layout (four 4 KiB row pieces per workgroup); bytes written per second.
+    workgroups_per_cu (3..7): resident workgroups capped by unused dynamic LDS, as the decode kernels' launches do"""
     import torch
     lib = load()
+    lib.hbmref_set_fill_image_lds.argtypes = [ctypes.c_uint]
+    lib.hbmref_set_fill_image_lds(((163840 // workgroups_per_cu) & ~2047) if workgroups_per_cu else 0)
     nbytes = width_bytes * height
     buf = torch.empty((pitch_bytes or width_bytes) * height, dtype=torch.uint8, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -137,14 +137,18 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill_unaligned(void
 
 // width_bytes x height image (width a multiple of 4096 bytes, height of 4 rows), rows pitch_bytes apart (0 = dense; a multiple
 // of 16), pattern 0 or 2
+// lds_bytes: unused dynamic LDS per workgroup -- caps the resident workgroups per CU (160 KiB per CU), the launch-time handle the
+// decode kernels use as well
+static unsigned g_fill_image_lds = 0;
+extern "C" __attribute__((visibility("default"))) void hbmref_set_fill_image_lds(unsigned lds_bytes) { g_fill_image_lds = lds_bytes; }
 extern "C" __attribute__((visibility("default"))) int hbmref_fill_image(void *dst, size_t width_bytes, size_t height, size_t pitch_bytes, int pattern, uint32_t seed, void *stream) {
 	if (pitch_bytes == 0) pitch_bytes = width_bytes;
 	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || pitch_bytes % 16u || pitch_bytes < width_bytes || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
 	const uint32_t tiles_per_row = (uint32_t)(width_bytes / 4096u), pitch_vectors = (uint32_t)(pitch_bytes / 16u);
 	const dim3 grid((unsigned)(tiles_per_row * (height / 4u))), block(256);
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	if (pattern == 0) hipLaunchKernelGGL((fill_image_kernel<0>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
-	else hipLaunchKernelGGL((fill_image_kernel<2>), grid, block, 0, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
+	if (pattern == 0) hipLaunchKernelGGL((fill_image_kernel<0>), grid, block, g_fill_image_lds, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
+	else hipLaunchKernelGGL((fill_image_kernel<2>), grid, block, g_fill_image_lds, s, static_cast<v4 *>(dst), pitch_vectors, tiles_per_row, seed);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
