@@ -217,8 +217,16 @@ def stream_c(fmt, wb, hb):
 def make_stream(kind, fmt, wb, hb, seed=None):
     """'U', 'M' or 'C' stream of wb x hb blocks (None if the kind does not exist for fmt).  Measurement-only kinds: 'Z' all-zero
     blocks (every pixel decodes to zero for the formats it is used with), 'S' stream C with the fixture's blocks shuffled (same
-    blocks, same modes, no spatial coherence), 'K' one block of stream U repeated (constant image)."""
+    blocks, same modes, no spatial coherence), 'K' one block of stream U repeated (constant image), 'm0'..'m7' stream U with every
+    BPTC block forced to that mode (uniform waves, random content)."""
     import oracle_lib as ol
+    if len(kind) == 2 and kind[0] == "m":
+        if fmt.name != "BPTC":
+            return None
+        b = np.array(ol.stream_u(fmt, wb * hb, seed=seed), dtype=np.uint8).reshape(-1, fmt.block_bytes)
+        m = int(kind[1])
+        b[:, 0] = (b[:, 0] & np.uint8((0xFF << (m + 1)) & 0xFF)) | np.uint8(1 << m)
+        return b.reshape(-1)
     if kind == "C":
         return stream_c(fmt, wb, hb)
     if kind == "Z":
