@@ -28,6 +28,10 @@ namespace detexhip {
 template <class Dec, class = void> struct WavesPerSimd { static constexpr int value = 1; };
 template <class Dec> struct WavesPerSimd<Dec, std::enable_if_t<(Dec::kWavesPerSimd > 0)>> { static constexpr int value = Dec::kWavesPerSimd; };
 
+// the same for kernels that add a staging array of their own to the decoder's LDS: four workgroups per CU are then all that fit,
+// and asking the register allocator for more waves than that only takes registers away
+template <class Dec> struct WavesPerSimdStaged { static constexpr int value = WavesPerSimd<Dec>::value > 4 ? 4 : WavesPerSimd<Dec>::value; };
+
 // decoders that deliver sixteen zero pixels themselves when they return false (Dec::kZeroOnFailure)
 template <class Dec, class = void> struct ZeroOnFailure { static constexpr bool value = false; };
 template <class Dec> struct ZeroOnFailure<Dec, std::enable_if_t<Dec::kZeroOnFailure>> { static constexpr bool value = true; };
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 // textures need no separate edge pass.  Needs rows that are dword-aligned and a whole number of dwords long; anything else
 // (R8 / RG8 / RGB8 images of odd width) goes pixel by pixel through decode_linear_clipped.
 template <class Dec, int EPI>
-__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_staged(const void *__restrict__ blocks,
+__global__ __launch_bounds__(256, WavesPerSimdStaged<Dec>::value) void decode_linear_staged(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t row_bytes, uint32_t height, uint64_t pitch,
 		uint32_t *__restrict__ status, uint32_t tiles_per_row, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
@@ -567,7 +571,8 @@ __global__ __launch_bounds__(256) void decode_linear_clipped(const void *__restr
 // ---- block-major output (detexDecompressTextureTiled, texture.c:77-98) and the batched form of
 // the per-block API (mode_mask / flags honoured, per-block ok byte) ----------------------------
 template <class Dec, int EPI, bool CHECKED>
-__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_blocks(const void *__restrict__ blocks,
+__global__ __launch_bounds__(256, (OwnStage<Dec>::value && EpilogueOf<Dec, EPI>::kRowDwords == 4 ? WavesPerSimd<Dec>::value : WavesPerSimdStaged<Dec>::value))
+void decode_blocks(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask, uint32_t flags,
 		uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;	// = 16-byte vectors per decoded block
