@@ -217,7 +217,7 @@ def stream_c(fmt, wb, hb):
 def make_stream(kind, fmt, wb, hb, seed=None):
     """'U', 'M' or 'C' stream of wb x hb blocks (None if the kind does not exist for fmt).  Measurement-only kinds: 'Z' all-zero
     blocks (every pixel decodes to zero for the formats it is used with), 'S' stream C with the fixture's blocks shuffled (same
-    blocks, same modes, no spatial coherence), 'K' one block of stream U repeated (constant image), 'm0'..'m7' stream U with every
+    blocks, same modes, no spatial coherence), 'K' one block of stream U repeated (constant image), 'F' the unsigned BC6H fixture as signed BC6H blocks, 'm0'..'m7' stream U with every
     BPTC block forced to that mode (uniform waves, random content)."""
     import oracle_lib as ol
     if len(kind) == 2 and kind[0] == "m":
@@ -229,6 +229,10 @@ def make_stream(kind, fmt, wb, hb, seed=None):
         return b.reshape(-1)
     if kind == "C":
         return stream_c(fmt, wb, hb)
+    if kind == "F":     # measurement only: signed BC6H fed the unsigned format's fixture (the same block syntax; coherent content)
+        if fmt.name != "BPTC_SIGNED_FLOAT":
+            return None
+        return stream_c(F.BY_NAME["BPTC_FLOAT"], wb, hb)
     if kind == "Z":
         return np.zeros(wb * hb * fmt.block_bytes, np.uint8)
     if kind == "S":
