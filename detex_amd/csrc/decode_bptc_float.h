@@ -296,11 +296,17 @@ DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t fla
 	return Bc6hParams{ ubfe(mw.a, 16, 5), transformed ? rw : 0u, transformed ? gw : 0u, transformed ? bw : 0u };
 }
 
-// decompress-bptc-float.c:52-63
-DH int32_t bc6h_unquantize_unsigned(uint32_t x, uint32_t epb) {
-	const uint32_t mid = ((x << 15) + 0x4000u) >> ((epb - 1u) & 31u);
-	uint32_t u = x == 0u ? 0u : (x == (1u << epb) - 1u ? 0xFFFFu : mid);
-	return (int32_t)(epb >= 16u ? x : u);
+// decompress-bptc-float.c:52-63: U(0) = 0, U(2^epb - 1) = 0xFFFF, otherwise ((x << 15) + 0x4000) >> (epb - 1); epb = 16 passes the
+// value through.  Both terms of the middle case are multiples of 2^(epb-1) (epb <= 15 there), so it is (2x + 1) << (15 - epb)
+// = (x << sh) + c exactly, sh = 16 - epb, c = 2^(15-epb); the two special values differ from it by -c (at 0) and by + c - 1 (at
+// the maximum, where x + 1 = 2^epb).  All of it as two multiply-adds, no compare and no select -- the literal form cost two
+// compares and three v_cndmask_b32 per value, whose VOP2 encoding issues at a fraction of the rate (dev_common.h):
+//   U(x) = (x << sh) + min(x, 1) * c + ((x + 1) >> epb) * (c - 1),   c = 0 = c - 1 for epb = 16
+struct Bc6hUnsignedUnq { uint32_t epb, sh, c, cm; };	// per block
+DH Bc6hUnsignedUnq bc6h_unsigned_unq(uint32_t epb) { return Bc6hUnsignedUnq{ epb, 16u - epb, 0x8000u >> epb, 0x7FFFu >> epb }; }
+DH int32_t bc6h_unquantize_unsigned(uint32_t x, const Bc6hUnsignedUnq &k) {
+	const uint32_t mid = DETEX_UMUL24(min(x, 1u), k.c) + (x << k.sh);
+	return (int32_t)(DETEX_UMUL24((x + 1u) >> k.epb, k.cm) + mid);
 }
 // decompress-bptc-float.c:65-86: sign(x) * U(|x|) with U(0) = 0, U(a) = 0x7FFF for a >= lim = 2^(epb-1) - 1, else
 // ((a << 15) + 0x4000) >> (epb - 1).  Both terms of that middle case are multiples of 2^(epb-1) (epb <= 15 there), so it is
@@ -384,30 +390,22 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		const uint32_t delta[3] = { p.dr, p.dg, p.db };
 		int32_t q[3][4];
 		const Bc6hSignedUnq sk = bc6h_signed_unq(p.epb);
-		// signed, :487-518 in one form for transformed and untransformed modes: value = sext_epb(base' + sext_w(field)) with
-		// (base', w) = (base, delta width) or (0, epb) -- the wrap to epb bits and the sign extension are one v_bfe_i32
+		const Bc6hUnsignedUnq uk = bc6h_unsigned_unq(p.epb);
+		// :487-518 in one form for transformed and untransformed modes: value = ext_epb(base' + sext_w(field)) with (base', w) =
+		// (base, delta width) or (0, the whole field: epb for the signed format, 31 bits for the unsigned one, whose fields are
+		// less than 2^16) -- the wrap to epb bits and the sign / zero extension are one v_bfe
 		int32_t base_t[3];
 		uint32_t width_t[3];
-		if (SIGNED) {
 #pragma unroll
-			for (int c = 0; c < 3; c++) {
-				base_t[c] = delta[c] ? sbfe(ep[c][0], 0, p.epb) : 0;
-				width_t[c] = delta[c] ? delta[c] : p.epb;
-			}
+		for (int c = 0; c < 3; c++) {
+			base_t[c] = delta[c] ? (SIGNED ? sbfe(ep[c][0], 0, p.epb) : (int32_t)ep[c][0]) : 0;
+			width_t[c] = delta[c] ? delta[c] : (SIGNED ? p.epb : 31u);
 		}
 		// :487-518 sign extension and delta transform, :520-533 unquantisation
 		auto endpoint = [&](int c, int e) {
-			int32_t v;
-			if (SIGNED) {
-				v = e == 0 ? sbfe(ep[c][0], 0, p.epb) : sbfe((uint32_t)(base_t[c] + sbfe(ep[c][e], 0, width_t[c])), 0, p.epb);
-			} else {
-				v = (int32_t)ep[c][0];
-				if (e > 0) {
-					const uint32_t t = ubfe((uint32_t)(v + sbfe(ep[c][e], 0, delta[c])), 0, p.epb);
-					v = (int32_t)(delta[c] ? t : ep[c][e]);
-				}
-			}
-			q[c][e] = SIGNED ? bc6h_unquantize_signed_x4(v, sk) : bc6h_unquantize_unsigned((uint32_t)v, p.epb);	// signed: 4 * value
+			const uint32_t sum = e == 0 ? ep[c][0] : (uint32_t)(base_t[c] + sbfe(ep[c][e], 0, width_t[c]));
+			q[c][e] = SIGNED ? bc6h_unquantize_signed_x4(sbfe(sum, 0, p.epb), sk)			// signed: 4 * value
+				: bc6h_unquantize_unsigned(e == 0 ? sum : ubfe(sum, 0, p.epb), uk);
 		};
 #pragma unroll
 		for (int c = 0; c < 3; c++) { endpoint(c, 0); endpoint(c, 1); q[c][2] = 0; q[c][3] = 0; }
@@ -439,10 +437,13 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 			// signed: q[] holds 4 * value, so that the 16 result bits of (base + w * diff) >> 6 are bytes 1-2 of the sum
 			// (|sum| < 2^23, 4 * |diff| < 2^19: still inside v_mad_i32_i24's operands) and one v_perm_b32 both drops the
 			// six fraction bits and packs two channels -- no shifts in the texel loop
-			constexpr int kRound = SIGNED ? 128 : 32;
-			ra.x = (uint32_t)(q[0][2 * s] * 64 + kRound);
-			ra.y = (uint32_t)(q[1][2 * s] * 64 + kRound);
-			ra.z = (uint32_t)(q[2][2 * s] * 64 + kRound);
+			// unsigned: base = (64 * e0 + 32) << 10 < 2^32, and the texel loop multiplies diff by the weight << 10, so that the
+			// value (64 * e0 + 32 + w * diff) >> 6 < 2^16 is the HIGH HALF of the sum: the next multiply reads it there
+			// (v_mul_u32_u24 with src0_sel:WORD_1), no shift
+			constexpr int kScale = SIGNED ? 64 : 65536, kRound = SIGNED ? 128 : 32768;
+			ra.x = (uint32_t)q[0][2 * s] * (uint32_t)kScale + (uint32_t)kRound;
+			ra.y = (uint32_t)q[1][2 * s] * (uint32_t)kScale + (uint32_t)kRound;
+			ra.z = (uint32_t)q[2][2 * s] * (uint32_t)kScale + (uint32_t)kRound;
 			ra.w = (uint32_t)(q[0][2 * s + 1] - q[0][2 * s]);
 			rb.x = (uint32_t)(q[1][2 * s + 1] - q[1][2 * s]);
 			rb.y = (uint32_t)(q[2][2 * s + 1] - q[2][2 * s]);
@@ -457,14 +458,15 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			if (i == 8) { win = win_hi; stage_priority<Tune::kBc6hPrio, 2>(); }
-			const int32_t w = (int32_t)((DETEX_UMUL24(win & imask, wmul) + wadd) >> 16);
+			const uint32_t t = DETEX_UMUL24(win & imask, wmul) + wadd;		// the weight is the high half
+			const int32_t w = SIGNED ? (int32_t)(t >> 16) : (int32_t)high_half_shl<10>(t);	// unsigned: weight << 10 (<= 2^16)
 			win >>= ibits;
 			uint4 ra; uint2 rb;
 			lane.get(p12 >> i, p11 >> i, ra, rb);
 			const int32_t bs[3] = { (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z }, df[3] = { (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y };
 			int32_t v[3];
 #pragma unroll
-			for (int c = 0; c < 3; c++) v[c] = SIGNED ? bs[c] + __mul24(w, df[c]) : (bs[c] + __mul24(w, df[c])) >> 6;
+			for (int c = 0; c < 3; c++) v[c] = (int32_t)((uint32_t)bs[c] + (uint32_t)__mul24(w, df[c]));	// unsigned: (value << 16) | fraction
 			if (SIGNED) {
 				// :576-609 sign-magnitude half: m = (|v|*31)>>5 = |v| - ceil(|v|/32), sign bit only if m != 0.  Every v fits a
 				// signed 16-bit lane (|v| <= 0x8000, and 0x8000 still comes out right in the unsigned steps), so R,G of this
@@ -479,12 +481,13 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 					d[2 * i + 1] = hb >> 16;
 				}
 			} else {
+				// :613-621: half = value * 31 / 64 (value >= 0) = bytes 1-2 of value * 124 < 2^23; the v_perm that packs R and G
+				// takes them from there, so only B needs a shift
 				uint32_t h[3];
 #pragma unroll
-				for (int c = 0; c < 3; c++) h[c] = (uint32_t)__mul24(v[c], 31) >> 6;	// :613-621 (v >= 0: /64 == >>6)
-				d[2 * i] = perm(h[1], h[0], 0x05040100u);	// every h < 2^16; v_perm keeps the compiler from fusing
-										// the shift into a v_mul_lo_u32
-				d[2 * i + 1] = h[2];				// X = 0
+				for (int c = 0; c < 3; c++) h[c] = DETEX_UMUL24((uint32_t)v[c] >> 16, 124u);
+				d[2 * i] = perm(h[1], h[0], 0x06050201u);
+				d[2 * i + 1] = h[2] >> 8;			// X = 0
 			}
 		}
 		return valid;

@@ -100,6 +100,17 @@ DH uint32_t and3(uint32_t a, uint32_t b, uint32_t c) { return a & b & c; }
 #endif
 // byte permute: result byte i = byte sel[i] of the 8-byte pool {s0 (4..7), s1 (0..3)}; 0x0C -> 0x00
 DH uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// the high 16-bit half of v shifted left by S: ONE v_lshlrev_b32 with sub-dword source selection (SDWA src1_sel:WORD_1); the
+// compiler's own form of (v >> 16) << S is a shift and a mask
+template <int S> DH uint32_t high_half_shl(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t r;
+	asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "n"(S), "v"(v));
+	return r;
+#else
+	return (v >> 16) << S;
+#endif
+}
 DH int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
 DH uint32_t clamp255(int32_t v) { return (uint32_t)clampi(v, 0, 255); }
 DH uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
