@@ -305,7 +305,7 @@ DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t fla
 struct Bc6hUnsignedUnq { uint32_t epb, sh, c, cm; };	// per block
 DH Bc6hUnsignedUnq bc6h_unsigned_unq(uint32_t epb) { return Bc6hUnsignedUnq{ epb, 16u - epb, 0x8000u >> epb, 0x7FFFu >> epb }; }
 DH int32_t bc6h_unquantize_unsigned(uint32_t x, const Bc6hUnsignedUnq &k) {
-	const uint32_t mid = DETEX_UMUL24(min(x, 1u), k.c) + (x << k.sh);
+	const uint32_t mid = DETEX_UMUL24(nonzero_as_one(x), (x << k.sh) + k.c);
 	return (int32_t)(DETEX_UMUL24((x + 1u) >> k.epb, k.cm) + mid);
 }
 // decompress-bptc-float.c:65-86: sign(x) * U(|x|) with U(0) = 0, U(a) = 0x7FFF for a >= lim = 2^(epb-1) - 1, else
@@ -346,6 +346,7 @@ DH uint32_t bc6h_sign_magnitude_pk(uint32_t p, uint32_t sign_bits) {
 // default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8, kNative = SIGNED ? kNatOther : kNatFloatRGBX16;
+	static constexpr int kWavesPerSimd = Tune::kBc6hWavesPerSimd;
 	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626
@@ -357,8 +358,9 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[32]) {
 		// :23-33: 2-bit codes 00/01 = modes 0/1, otherwise a 5-bit code; 10011,10111,11011,11111 reserved
 		stage_priority<Tune::kBc6hPrio, 0>();
-		const uint32_t low2 = blk.x & 3u, low5 = blk.x & 0x1Fu;
-		const uint32_t coded = low2 < 2u ? low2 : (low2 == 2u ? 2u + (low5 >> 2) : 10u + (low5 >> 2));
+		// (as arithmetic: the compiler turns the conditional form into three exec-mask branches)  codes ..10 -> 2 + bits 2-4, ..11 -> 10 + bits 2-4
+		const uint32_t low2 = blk.x & 3u;
+		const uint32_t coded = bfi(bit_to_mask(blk.x, 1), 2u + ubfe(blk.x, 2, 3) + ((blk.x & 1u) << 3), low2);
 		const bool valid = coded <= 13u && (!CHECKED || (mode_mask & (1u << (coded & 31u))) != 0u);
 		const uint32_t keep = cond_to_mask(valid);
 		blk.x &= keep; blk.y &= keep; blk.z &= keep; blk.w &= keep;

@@ -111,6 +111,16 @@ template <int S> DH uint32_t high_half_shl(uint32_t v) {
 	return (v >> 16) << S;
 #endif
 }
+// min(v, 1) as ONE v_min_u32 (the compiler canonicalises it to compare + select)
+DH uint32_t nonzero_as_one(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t r;
+	asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+	return r;
+#else
+	return v ? 1u : 0u;
+#endif
+}
 DH int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
 DH uint32_t clamp255(int32_t v) { return (uint32_t)clampi(v, 0, 255); }
 DH uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }

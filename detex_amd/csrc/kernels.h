@@ -286,10 +286,11 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 		const v4 a = slab[src_a], b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		if (ia < n_blocks) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a + (uint64_t)r * pitch));
+		if (ia < n_blocks) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a));
 		store_pause();
-		if (ib < n_blocks) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b + (uint64_t)r * pitch));
+		if (ib < n_blocks) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b));
 		store_pause();
+		dst_a += pitch; dst_b += pitch;			// (one 64-bit add each; r * pitch came out as two v_mad_u64_u32 per pointer)
 	}
 }
 
@@ -368,6 +369,10 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	pin_block(blk);
 	if constexpr (ROW == 8 && NT) {
 		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
+		// (The branch around the decode costs ~30 v_mov: the compiler initialises the result registers for the lanes that skip it.
+		// Decoding unconditionally -- the lanes past the end have a copy of the last block -- removes them, and with the branch
+		// gone the scheduler treats decode and exchange as one region and allocates 126 VGPRs instead of 65: four workgroups per
+		// CU instead of seven, BC6H on coherent content 80 -> 91 us.  The branch stays.)
 		const bool live = i < n_blocks;
 		uint32_t o[4 * ROW];
 		bool ok = true;

@@ -19,8 +19,9 @@ struct ProductTune {
 	static constexpr int kBc7UniformTexelGroup = 4;	// subset rows requested together in the per-record copies (1 in the mixed-mode path)
 	static constexpr bool kBc7OwnStage = true;
 	static constexpr int kBc7Prio = 0;
-	// BC6H: the same priority staging
+	// BC6H: the same priority staging; register budget in waves per SIMD (0 = the compiler's choice)
 	static constexpr int kBc6hPrio = 0;
+	static constexpr int kBc6hWavesPerSimd = 0;
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of detexhip.hip (kFormats), 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
 	static constexpr int kWorkgroupsPerCu = -1;
