@@ -347,6 +347,7 @@ DH uint32_t bc6h_sign_magnitude_pk(uint32_t p, uint32_t sign_bits) {
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8, kNative = SIGNED ? kNatOther : kNatFloatRGBX16;
 	static constexpr int kWavesPerSimd = Tune::kBc6hWavesPerSimd;
+	static constexpr bool kRowWise = true;
 	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626
@@ -356,6 +357,15 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	// sixteen carries a reserved mode) is not needed (kernels.h: decode_word)
 	static constexpr bool kZeroOnFailure = true;
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[32]) {
+		return decode_rows<CHECKED>(blk, mode_mask, flags, [&](int r, const uint32_t (&row)[8]) {
+#pragma unroll
+			for (int k = 0; k < 8; k++) d[8 * r + k] = row[k];
+		});
+	}
+	// the same, handing each texel row (four pixels, eight dwords) to `sink(r, row)` as soon as it is complete: the linear
+	// kernel exchanges and stores a row while the next ones are still being interpolated, and never holds all 32 result dwords
+	template <bool CHECKED, class Sink> static DH bool decode_rows(uint4 blk, uint32_t mode_mask, uint32_t flags, Sink &&sink) {
+		uint32_t d[8];			// the current texel row
 		// :23-33: 2-bit codes 00/01 = modes 0/1, otherwise a 5-bit code; 10011,10111,11011,11111 reserved
 		stage_priority<Tune::kBc6hPrio, 0>();
 		// (as arithmetic: the compiler turns the conditional form into three exec-mask branches)  codes ..10 -> 2 + bits 2-4, ..11 -> 10 + bits 2-4
@@ -474,13 +484,13 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 				// signed 16-bit lane (|v| <= 0x8000, and 0x8000 still comes out right in the unsigned steps), so R,G of this
 				// texel and B of two neighbouring texels are finished two per VGPR; bit 15 of m + 0x7FFF is set iff m != 0.
 				// v[] are the sums times 4 here: value c = bits 8-23
-				d[2 * i] = bc6h_sign_magnitude_pk(perm((uint32_t)v[1], (uint32_t)v[0], 0x06050201u), sign_bits);
+				d[2 * (i & 3)] = bc6h_sign_magnitude_pk(perm((uint32_t)v[1], (uint32_t)v[0], 0x06050201u), sign_bits);
 				if ((i & 1) == 0) {
 					b_even = (uint32_t)v[2];
 				} else {
 					const uint32_t hb = bc6h_sign_magnitude_pk(perm((uint32_t)v[2], b_even, 0x06050201u), sign_bits);
-					d[2 * i - 1] = hb & 0xFFFFu;		// X = 0
-					d[2 * i + 1] = hb >> 16;
+					d[2 * (i & 3) - 1] = hb & 0xFFFFu;		// X = 0
+					d[2 * (i & 3) + 1] = hb >> 16;
 				}
 			} else {
 				// :613-621: half = value * 31 / 64 (value >= 0) = bytes 1-2 of value * 124 < 2^23; the v_perm that packs R and G
@@ -488,9 +498,10 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 				uint32_t h[3];
 #pragma unroll
 				for (int c = 0; c < 3; c++) h[c] = DETEX_UMUL24((uint32_t)v[c] >> 16, 124u);
-				d[2 * i] = perm(h[1], h[0], 0x06050201u);
-				d[2 * i + 1] = h[2] >> 8;			// X = 0
+				d[2 * (i & 3)] = perm(h[1], h[0], 0x06050201u);
+				d[2 * (i & 3) + 1] = h[2] >> 8;			// X = 0
 			}
+			if ((i & 3) == 3) sink(i >> 2, d);
 		}
 		return valid;
 	}

@@ -40,6 +40,10 @@ template <class Dec> struct ZeroOnFailure<Dec, std::enable_if_t<Dec::kZeroOnFail
 template <class Dec, class = void> struct OwnStage { static constexpr bool value = false; };
 template <class Dec> struct OwnStage<Dec, std::enable_if_t<Dec::kOwnStage>> { static constexpr bool value = true; };
 
+// decoders that can hand over texel rows as they complete (Dec::kRowWise, Dec::decode_rows)
+template <class Dec, class = void> struct RowWise { static constexpr bool value = false; };
+template <class Dec> struct RowWise<Dec, std::enable_if_t<Dec::kRowWise>> { static constexpr bool value = true; };
+
 // blocks per lane in the linear fast path (Dec::kLaneBlocks; default 1): see decode_linear_grouped
 template <class Dec, class = void> struct LaneBlocks { static constexpr int value = 1; };
 template <class Dec> struct LaneBlocks<Dec, std::enable_if_t<(Dec::kLaneBlocks > 1)>> { static constexpr int value = Dec::kLaneBlocks; };
@@ -255,28 +259,35 @@ DH void split_index(uint32_t i, uint32_t width_in_blocks, uint32_t &by, uint32_t
 // as for the 32-bit formats.  Works for any width: output vector e of the wave belongs to block first + e/2,
 // whose place in the image is recomputed by the storing lane (a wave that straddles the end of a block row
 // simply continues on the next one); every lane of the wave must call this, `live` or not.
-DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks,
-		bool live, const uint32_t (&o)[32]) {
+struct WideRowStore {
 	typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 	// [half of the lane's 32-byte row][lane], the second half 72 vectors on: writes (consecutive lanes) and
 	// transposed reads (output vector e = 2*lane' + half) are both bank-conflict free
-	constexpr int STRIDE = 72;
-	__shared__ v4 xpose[4][STRIDE + 64];
-	v4 *slab = xpose[threadIdx.x >> 6];
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t src_a = (lane & 1u) * STRIDE + (lane >> 1), src_b = src_a + 32u;	// vectors e = lane and e = 64 + lane
-	// destinations of those two vectors: blocks first + lane/2 and first + 32 + lane/2
-	const uint32_t ia = first + (lane >> 1), ib = ia + 32u;
-	uint32_t by, bx;
-	split_index(ia, width_in_blocks, by, bx);
-	uint8_t *dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
-	split_index(ib, width_in_blocks, by, bx);
-	uint8_t *dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
-#pragma unroll
-	for (int r = 0; r < 4; r++) {
-		if (live) {
-			slab[lane] = v4{ o[8 * r], o[8 * r + 1], o[8 * r + 2], o[8 * r + 3] };
-			slab[STRIDE + lane] = v4{ o[8 * r + 4], o[8 * r + 5], o[8 * r + 6], o[8 * r + 7] };
+	static constexpr int STRIDE = 72;
+	v4 *slab;
+	uint32_t lane, src_a, src_b;
+	uint8_t *dst_a, *dst_b;
+	uint64_t pitch;
+	bool store_a, store_b;
+	DH WideRowStore(uint8_t *pixels, uint64_t pitch_, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks) : pitch(pitch_) {
+		__shared__ v4 xpose[4][STRIDE + 64];
+		slab = xpose[threadIdx.x >> 6];
+		lane = threadIdx.x & 63u;
+		src_a = (lane & 1u) * STRIDE + (lane >> 1); src_b = src_a + 32u;	// vectors e = lane and e = 64 + lane
+		// destinations of those two vectors: blocks first + lane/2 and first + 32 + lane/2
+		const uint32_t ia = first + (lane >> 1), ib = ia + 32u;
+		uint32_t by, bx;
+		split_index(ia, width_in_blocks, by, bx);
+		dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+		split_index(ib, width_in_blocks, by, bx);
+		dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+		store_a = ia < n_blocks; store_b = ib < n_blocks;
+	}
+	// the next texel row of the wave (rows must come in order 0..3); `mine`: this lane has a decoded row to contribute
+	DH void row(bool mine, const uint32_t *o) {
+		if (mine) {
+			slab[lane] = v4{ o[0], o[1], o[2], o[3] };
+			slab[STRIDE + lane] = v4{ o[4], o[5], o[6], o[7] };
 		}
 		// same wave: LDS operations complete in order; the wavefront-scope fences only keep the
 		// compiler from reordering or forwarding across the exchange (they emit no cache traffic)
@@ -286,12 +297,18 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 		const v4 a = slab[src_a], b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		if (ia < n_blocks) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a));
+		if (store_a) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a));
 		store_pause();
-		if (ib < n_blocks) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b));
+		if (store_b) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b));
 		store_pause();
 		dst_a += pitch; dst_b += pitch;			// (one 64-bit add each; r * pitch came out as two v_mad_u64_u32 per pointer)
 	}
+};
+DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks,
+		bool live, const uint32_t (&o)[32]) {
+	WideRowStore st(pixels, pitch, width_in_blocks, first, n_blocks);
+#pragma unroll
+	for (int r = 0; r < 4; r++) st.row(live, o + 8 * r);
 }
 
 // The block of lane i as ONE 8/16-byte load: left to itself the compiler loads the first dword, tests the decoders'
@@ -374,12 +391,24 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		// gone the scheduler treats decode and exchange as one region and allocates 126 VGPRs instead of 65: four workgroups per
 		// CU instead of seven, BC6H on coherent content 80 -> 91 us.  The branch stays.)
 		const bool live = i < n_blocks;
-		uint32_t o[4 * ROW];
-		bool ok = true;
-		if (live) ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, decode_flags, o);
-		if (stores_enabled(o))
-			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
-		if (live) raise_status(!ok, status);
+		if constexpr (RowWise<Dec>::value && EPI == kEpiNone && !Tune::kNoCompute && !Tune::kNoStore && Tune::kRowWise) {
+			// MEASUREMENT BUILDS ONLY (Tune::kRowWise): each texel row is exchanged and stored as soon as the decoder has it,
+			// while the following rows are still being interpolated -- the 32 result dwords are never all alive (28 VALU operations
+			// fewer per wave), and the wave's eight store instructions are spread over the second half of its life.  That spreading
+			// is the wrong thing to do: 8192^2 BC6H 93.6 / 93.7 / 94.1 us (U / M / C) against 82.8 / 83.3 / 86.2 for the eight stores
+			// in one burst at the end.  Every lane decodes here (those past the end a copy of the last
+			// block) because every lane stores: output vector e of the wave is written by lane e whoever decoded it.
+			WideRowStore st(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks);
+			const bool ok = Dec::template decode_rows<false>(blk, 0xFFFFFFFFu, decode_flags, [&](int, const uint32_t (&row)[8]) { st.row(true, row); });
+			if (live) raise_status(!ok, status);
+		} else {
+			uint32_t o[4 * ROW];
+			bool ok = true;
+			if (live) ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, decode_flags, o);
+			if (stores_enabled(o))
+				store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
+			if (live) raise_status(!ok, status);
+		}
 	} else {
 		if (i >= n_blocks) return;
 		uint32_t o[4 * ROW];

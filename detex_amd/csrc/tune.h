@@ -22,6 +22,9 @@ struct ProductTune {
 	// BC6H: the same priority staging; register budget in waves per SIMD (0 = the compiler's choice)
 	static constexpr int kBc6hPrio = 0;
 	static constexpr int kBc6hWavesPerSimd = 0;
+	// BC6H linear kernel: texel rows exchanged and stored as the decoder completes them (false: after the whole block -- the
+	// faster way round: DESIGN.md section 5)
+	static constexpr bool kRowWise = false;
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of detexhip.hip (kFormats), 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
 	static constexpr int kWorkgroupsPerCu = -1;

@@ -9,6 +9,7 @@
 #   grpN                    BC7: subset rows requested together in the per-record copies
 #   bc7stage                block-major BC7 with the separate 17 KiB staging array
 #   bc6wavesN               BC6H register budget (waves per SIMD)
+#   rowwise                 BC6H linear kernel: texel rows exchanged and stored as the decoder completes them
 #   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
 #   sgprconst               v_bitop3 masks left in SGPRs
 #   rgtc1gN                 RGTC1 blocks per lane
@@ -35,6 +36,7 @@ for v in "$@"; do
       plain) body+="static constexpr bool kBc7Uniform = false; " ;;
       bc7stage) body+="static constexpr bool kBc7OwnStage = false; " ;;
       prio*) body+="static constexpr int kBc7Prio = ${k#prio}; " ;;
+      rowwise) body+="static constexpr bool kRowWise = true; " ;;
       bc6waves*) body+="static constexpr int kBc6hWavesPerSimd = ${k#bc6waves}; " ;;
       bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;
       sgprconst) body+="static constexpr bool kMasksInVgprs = false; " ;;
