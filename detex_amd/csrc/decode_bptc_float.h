@@ -112,6 +112,14 @@ template <int M> DH Bc6hParams bc6h_mode(Bits128 b, uint32_t flags, uint32_t (&e
 // descriptor per mode in __constant__ memory, DERIVED AT COMPILE TIME from the spec strings above.
 constexpr int kLooseSrc[25] = { 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 39, 40, 49, 50, 59, 60, 69, 70, 75, 76 };
 struct Bc6hModeWords { uint32_t a, b, c, d; };	// a: w0 | rw<<4 | gw<<8 | bw<<12 | epb<<16 | transformed<<21; b,c,d: 15 x 5-bit routes
+// The routes again as RIGHT-SHIFT amounts, one byte per loose bit: slot s (destination bit kLooseDst[s] of its endpoint word) takes
+// bit `route` of the 25-bit candidate pool.  Slots 0-11 shift (pool << 5), slots 12-14 (pool << 10), right by (route + 5 - dst)
+// resp. route, which leaves the wanted bit AT its destination: one full-rate shift by a per-lane amount and one v_bitop3_b32 per
+// loose bit, where extracting the 5-bit route, extracting the bit and shifting it into place took three half-rate operations.
+// "No source" is amount 31: bit 31 of either shifted pool is a zero (pool bits >= 25 are), and it lands on bit 0, which no slot
+// with a non-zero destination keeps and which is 0 anyway.
+constexpr int kLooseDst[15] = { 4, 5, 4, 5, 4, 5, 0, 1, 2, 3, 4, 5, 10, 10, 10 };
+struct alignas(16) Bc6hRouteBytes { uint8_t amount[16]; };
 constexpr int bc6h_loose_slot(int comp, int ep, int bit) {
 	if (comp == 1 && ep == 2 && (bit == 4 || bit == 5)) return bit - 4;		// g2[4], g2[5]
 	if (comp == 1 && ep == 3 && (bit == 4 || bit == 5)) return 2 + bit - 4;		// g3[4], g3[5]
@@ -120,7 +128,7 @@ constexpr int bc6h_loose_slot(int comp, int ep, int bit) {
 	if (ep == 0 && bit == 10) return 12 + comp;					// r0[10], g0[10], b0[10]
 	return -1;
 }
-struct Bc6hDerived { Bc6hModeWords w; bool ok; };
+struct Bc6hDerived { Bc6hModeWords w; Bc6hRouteBytes r; bool ok; };
 constexpr Bc6hDerived bc6h_derive(int M) {
 	const Bc6hLayout L = bc6h_parse(kBc6hLayout[M], M < 2 ? 2 : 5);
 	constexpr int main_pos[3][4] = { { 5, 35, 65, 71 }, { 15, 45, 41, 51 }, { 25, 55, 61, -1 } };
@@ -151,7 +159,15 @@ constexpr Bc6hDerived bc6h_derive(int M) {
 	w.a = w0 | (w1[0] << 4) | (w1[1] << 8) | (w1[2] << 12) | ((uint32_t)kBc6hEpb[M] << 16) | ((transformed ? 1u : 0u) << 21);
 	for (int k = 0; k < 6; k++) { w.b |= route[k] << (5 * k); w.c |= route[6 + k] << (5 * k); }
 	for (int k = 0; k < 3; k++) w.d |= route[12 + k] << (5 * k);
-	return Bc6hDerived{ w, ok };
+	Bc6hRouteBytes r{};
+	for (int k = 0; k < 15; k++) {
+		const uint32_t none = 31u;
+		// (slots 12-14: the pool is shifted by 10, so candidates 22-24 would fall off the top: no layout routes them there)
+		if (k >= 12 && route[k] != none) ok = ok && route[k] <= 21u;
+		r.amount[k] = (uint8_t)(route[k] == none ? none : (k < 12 ? route[k] + 5u - (uint32_t)kLooseDst[k] : route[k]));
+	}
+	r.amount[15] = 31;
+	return Bc6hDerived{ w, r, ok };
 }
 #define BC6H_CHECK(M) static_assert(bc6h_derive(M).ok, "BC6H layout does not fit the canonical-position scheme")
 BC6H_CHECK(0); BC6H_CHECK(1); BC6H_CHECK(2); BC6H_CHECK(3); BC6H_CHECK(4); BC6H_CHECK(5); BC6H_CHECK(6);
@@ -161,6 +177,21 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 	bc6h_derive(0).w, bc6h_derive(1).w, bc6h_derive(2).w, bc6h_derive(3).w, bc6h_derive(4).w, bc6h_derive(5).w, bc6h_derive(6).w,
 	bc6h_derive(7).w, bc6h_derive(8).w, bc6h_derive(9).w, bc6h_derive(10).w, bc6h_derive(11).w, bc6h_derive(12).w, bc6h_derive(13).w,
 };
+__constant__ Bc6hRouteBytes kBc6hRouteBytes[14] = {
+	bc6h_derive(0).r, bc6h_derive(1).r, bc6h_derive(2).r, bc6h_derive(3).r, bc6h_derive(4).r, bc6h_derive(5).r, bc6h_derive(6).r,
+	bc6h_derive(7).r, bc6h_derive(8).r, bc6h_derive(9).r, bc6h_derive(10).r, bc6h_derive(11).r, bc6h_derive(12).r, bc6h_derive(13).r,
+};
+// index weights (bptc-tables.c aWeight3 / aWeight4) as bytes: entries 0-7 for 3-bit indices, 16-31 for 4-bit ones, so that a
+// texel's table address is (window & index mask) | base -- one v_bitop3_b32 -- and the weight one ds_read_u8
+struct alignas(32) Bc6hWeightBytes { uint8_t w[32]; };
+constexpr uint32_t bc6h_weight_of(uint32_t bits, uint32_t i) { return (i * bptc_weight_mul(bits) + bptc_weight_add(bits)) >> 16; }
+constexpr Bc6hWeightBytes bc6h_weight_bytes() {
+	Bc6hWeightBytes t = {};
+	for (uint32_t i = 0; i < 8u; i++) t.w[i] = (uint8_t)bc6h_weight_of(3, i);
+	for (uint32_t i = 0; i < 16u; i++) t.w[16u + i] = (uint8_t)bc6h_weight_of(4, i);
+	return t;
+}
+__constant__ Bc6hWeightBytes kBc6hWeightBytes = bc6h_weight_bytes();
 
 // ---- partition / index-stream table -----------------------------------------------------------------------
 // One entry per two-subset partition (5-bit partition number) plus entry 32 for the one-subset modes, everything the
@@ -172,8 +203,8 @@ __constant__ Bc6hModeWords kBc6hModeWords[14] = {
 //             (windows of 3-bit indices are 24 bits wide; one-subset blocks shift a zero word: `ones`); hshift = where
 //             the second window starts in the block's last dword (decompress-bptc-float.c:535-564)
 //   himask0   texel 0's own missing bit (bit 2 or 3 of the first window)
-//   wmul/wadd/imask/ibits   index width, mask and the closed-form weight constants (bptc_common.h)
-struct alignas(16) Bc6hPartEntry { uint32_t pmask12, route, himask0, ones, wmul, wadd, imask, ibits; };
+//   woff/imask/ibits   index width and mask, and where the weights of that width start in the byte table above
+struct alignas(16) Bc6hPartEntry { uint32_t pmask12, route, himask0, ones, woff, pad, imask, ibits; };
 struct Bc6hPartTable { Bc6hPartEntry e[33]; };
 constexpr Bc6hPartTable bc6h_part_table() {
 	Bc6hPartTable t = {};
@@ -182,9 +213,9 @@ constexpr Bc6hPartTable bc6h_part_table() {
 		const uint32_t lo = a < 8u ? 3u * a + 2u : 31u, hi = a >= 8u ? 3u * (a - 8u) + 2u : 31u;
 		const uint32_t half = 24u - (a < 8u ? 2u : 1u);			// index bits the first window consumes
 		t.e[p] = Bc6hPartEntry{ (uint32_t)kPartition1BitCx[p] << 12, lo | (hi << 5) | ((82u + half - 96u) << 10), 0xFFFFFFFFu << 2, 0xFFFFFFFFu,
-			bptc_weight_mul(3), bptc_weight_add(3), 7u, 3u };
+			0u, 0u, 7u, 3u };
 	}
-	t.e[32] = Bc6hPartEntry{ 0u, 31u | (31u << 5) | (0u << 10), 0xFFFFFFFFu << 3, 0u, bptc_weight_mul(4), bptc_weight_add(4), 15u, 4u };
+	t.e[32] = Bc6hPartEntry{ 0u, 31u | (31u << 5) | (0u << 10), 0xFFFFFFFFu << 3, 0u, 16u, 0u, 15u, 4u };
 	return t;
 }
 __constant__ Bc6hPartTable kBc6hPartTable = bc6h_part_table();
@@ -197,15 +228,20 @@ struct Bc6hLds {
 	uint2 row_b[2][256];		//                      diff g, b			(subset stride 2048: address bit 11)
 	Bc6hPartEntry part[33];
 	Bc6hModeWords modes[14];
+	Bc6hWeightBytes weights;	// (32-byte aligned: 33 * 32 + 14 * 16 = 1280)
+	Bc6hRouteBytes routes[14];
 };
-// both workgroup tables as one constant image: the copy is one 16-byte load and one ds_write_b128 for 80 threads
-struct alignas(16) Bc6hTables { Bc6hPartEntry part[33]; Bc6hModeWords modes[14]; };
-static_assert(sizeof(Bc6hTables) == 33 * 32 + 14 * 16 && offsetof(Bc6hLds, modes) - offsetof(Bc6hLds, part) == 33 * 32, "image = LDS layout");
+// the workgroup tables as one constant image: the copy is one 16-byte load and one ds_write_b128 for 96 threads
+struct alignas(32) Bc6hTables { Bc6hPartEntry part[33]; Bc6hModeWords modes[14]; Bc6hWeightBytes weights; Bc6hRouteBytes routes[14]; };
+static_assert(sizeof(Bc6hTables) == 33 * 32 + 14 * 16 + 32 + 14 * 16 && offsetof(Bc6hLds, modes) - offsetof(Bc6hLds, part) == 33 * 32 &&
+	offsetof(Bc6hLds, weights) - offsetof(Bc6hLds, part) == offsetof(Bc6hTables, weights) &&
+	offsetof(Bc6hLds, routes) - offsetof(Bc6hLds, part) == offsetof(Bc6hTables, routes), "image = LDS layout");
 constexpr Bc6hTables bc6h_tables() {
 	Bc6hTables t = {};
 	const Bc6hPartTable p = bc6h_part_table();
 	for (int k = 0; k < 33; k++) t.part[k] = p.e[k];
-	for (int k = 0; k < 14; k++) t.modes[k] = bc6h_derive(k).w;
+	for (int k = 0; k < 14; k++) { t.modes[k] = bc6h_derive(k).w; t.routes[k] = bc6h_derive(k).r; }
+	t.weights = bc6h_weight_bytes();
 	return t;
 }
 __constant__ Bc6hTables kBc6hTables = bc6h_tables();
@@ -217,6 +253,18 @@ DH void bc6h_prepare() {
 	__syncthreads();
 }
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return bc6h_lds().modes[mode]; }
+typedef __attribute__((address_space(3))) uint8_t bc6h_lds_u8;
+// shift amounts of a mode's loose bits: one address, fifteen ds_read_u8 with immediate offsets
+struct Bc6hRoutes {
+	uint32_t base;
+	DH explicit Bc6hRoutes(uint32_t mode) : base((uint32_t)(uintptr_t)bc6h_lds().routes + mode * (uint32_t)sizeof(Bc6hRouteBytes)) {}
+	template <int K> DH uint32_t amount() const { return ((const bc6h_lds_u8 *)(uintptr_t)base)[K]; }
+};
+// weight of the index in the low bits of `window`; `table` = bc6h_weight_table(woff), `imask` in a VGPR
+DH uint32_t bc6h_weight_table(uint32_t woff) { return (uint32_t)(uintptr_t)bc6h_lds().weights.w + woff; }
+DH uint32_t bc6h_weight(uint32_t table, uint32_t window, uint32_t imask) {
+	return *(const bc6h_lds_u8 *)(uintptr_t)(uint32_t)__builtin_amdgcn_bitop3_b32(window, imask, table, 0xEA);
+}
 struct Bc6hLane {
 	uint32_t base_a, base_b;
 	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -250,6 +298,13 @@ struct Bc6hLane {
 #else
 DH void bc6h_prepare() {}
 DH Bc6hModeWords bc6h_mode_words(uint32_t mode) { return kBc6hModeWords[mode]; }
+struct Bc6hRoutes {
+	uint32_t mode;
+	DH explicit Bc6hRoutes(uint32_t m) : mode(m) {}
+	template <int K> DH uint32_t amount() const { return kBc6hRouteBytes[mode].amount[K]; }
+};
+DH uint32_t bc6h_weight_table(uint32_t woff) { return woff; }
+DH uint32_t bc6h_weight(uint32_t table, uint32_t window, uint32_t imask) { return kBc6hWeightBytes.w[(window & imask) | table]; }
 struct Bc6hLane {
 	uint4 ra[2]; uint2 rb[2];
 	DH void put(int sub, uint4 a, uint2 b) { ra[sub] = a; rb[sub] = b; }
@@ -279,20 +334,27 @@ DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t fla
 	const uint32_t pool = field_at<2, 3>(b) | (field_at<11, 4>(b) << 3) | (field_at<21, 4>(b) << 7) | (field_at<31, 4>(b) << 11) |
 		(field_at<39, 2>(b) << 15) | (field_at<49, 2>(b) << 17) | (field_at<59, 2>(b) << 19) | (field_at<69, 2>(b) << 21) |
 		(field_at<75, 2>(b) << 23);
-	uint32_t bit[15];
-#pragma unroll
-	for (int k = 0; k < 15; k++) bit[k] = ubfe(pool, ubfe(k < 6 ? mw.b : (k < 12 ? mw.c : mw.d), 5 * (k % 6), 5), 1);
-	ep[1][2] = field_at<41, 4>(b) | (bit[0] << 4) | (bit[1] << 5);
-	ep[1][3] = field_at<51, 4>(b) | (bit[2] << 4) | (bit[3] << 5);
-	ep[2][2] = field_at<61, 4>(b) | (bit[4] << 4) | (bit[5] << 5);
-	ep[2][3] = bit[6] | (bit[7] << 1) | (bit[8] << 2) | (bit[9] << 3) | (bit[10] << 4) | (bit[11] << 5);
-	// one-subset modes: r0/g0/b0[10..] follow r1/g1/b1 bit-reversed (decompress-bptc-float.c:441-485)
-	const uint32_t hr = __brev(ubfe(win35, rw, 10u - rw)) >> ((22u + rw) & 31u);
-	const uint32_t hg = __brev(ubfe(win45, gw, 10u - gw)) >> ((22u + gw) & 31u);
-	const uint32_t hb = __brev(ubfe(win55, bw, 10u - bw)) >> ((22u + bw) & 31u);
-	ep[0][0] |= (one ? hr : bit[12]) << 10;
-	ep[1][0] |= (one ? hg : bit[13]) << 10;
-	ep[2][0] |= (one ? hb : bit[14]) << 10;
+	// each loose bit: the shifted pool moved right by the mode's amount for that slot puts it AT its destination (Bc6hRouteBytes)
+	const Bc6hRoutes routes(mode);
+	const uint32_t pool5 = pool << 5, pool10 = pool << 10;
+	uint32_t bit10 = 1u << 10;			// (not an inline constant: kept in a VGPR, see Bc6hLane::bit12)
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(bit10));
+#endif
+	ep[1][2] = and_or(pool5 >> routes.amount<0>(), 16u, and_or(pool5 >> routes.amount<1>(), 32u, field_at<41, 4>(b)));
+	ep[1][3] = and_or(pool5 >> routes.amount<2>(), 16u, and_or(pool5 >> routes.amount<3>(), 32u, field_at<51, 4>(b)));
+	ep[2][2] = and_or(pool5 >> routes.amount<4>(), 16u, and_or(pool5 >> routes.amount<5>(), 32u, field_at<61, 4>(b)));
+	ep[2][3] = and_or(pool5 >> routes.amount<6>(), 1u, and_or(pool5 >> routes.amount<7>(), 2u, and_or(pool5 >> routes.amount<8>(), 4u,
+		and_or(pool5 >> routes.amount<9>(), 8u, and_or(pool5 >> routes.amount<10>(), 16u, (pool5 >> routes.amount<11>()) & 32u)))));
+	// one-subset modes: r0/g0/b0[10..] follow r1/g1/b1 bit-reversed (decompress-bptc-float.c:441-485); they have no loose bits
+	// (every amount is 31), and the two-subset modes mask the reversed field away
+	const uint32_t one_mask = cond_to_mask(one);
+	const uint32_t hr = (__brev(ubfe(win35, rw, 10u - rw)) >> ((22u + rw) & 31u)) & one_mask;
+	const uint32_t hg = (__brev(ubfe(win45, gw, 10u - gw)) >> ((22u + gw) & 31u)) & one_mask;
+	const uint32_t hb = (__brev(ubfe(win55, bw, 10u - bw)) >> ((22u + bw) & 31u)) & one_mask;
+	ep[0][0] = and_or(pool10 >> routes.amount<12>(), bit10, ep[0][0]) | (hr << 10);
+	ep[1][0] = and_or(pool10 >> routes.amount<13>(), bit10, ep[1][0]) | (hg << 10);
+	ep[2][0] = and_or(pool10 >> routes.amount<14>(), bit10, ep[2][0]) | (hb << 10);
 	return Bc6hParams{ ubfe(mw.a, 16, 5), transformed ? rw : 0u, transformed ? gw : 0u, transformed ? bw : 0u };
 }
 
@@ -437,7 +499,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		win += win & pe.himask0;
 		win += win & (ones << (route & 31u));
 		win_hi += win_hi & (ones << ((route >> 5) & 31u));
-		const uint32_t ibits = pe.ibits, imask = pe.imask, wmul = pe.wmul, wadd = pe.wadd;
+		const uint32_t ibits = pe.ibits, imask = pe.imask, wtable = bc6h_weight_table(pe.woff);
 		// ((64-w)*e0 + w*e1 + 32) >> 6  ==  (64*e0 + 32 + w*(e1-e0)) >> 6  (:97-108): per subset keep
 		// base = 64*e0 + 32 and diff = e1 - e0 (a texel channel is one v_mad_i32_i24 + one shift) in per-lane LDS
 		// rows, fetched per texel by the partition bit
@@ -470,8 +532,9 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			if (i == 8) { win = win_hi; stage_priority<Tune::kBc6hPrio, 2>(); }
-			const uint32_t t = DETEX_UMUL24(win & imask, wmul) + wadd;		// the weight is the high half
-			const int32_t w = SIGNED ? (int32_t)(t >> 16) : (int32_t)high_half_shl<10>(t);	// unsigned: weight << 10 (<= 2^16)
+			// the weight from the byte table in LDS (one v_bitop3_b32 for the address; the closed form cost an `and`, a multiply-add
+			// and a shift, two of them half-rate); unsigned: weight << 10 (<= 2^16)
+			const int32_t w = (int32_t)(bc6h_weight(wtable, win, imask) << (SIGNED ? 0 : 10));
 			win >>= ibits;
 			uint4 ra; uint2 rb;
 			lane.get(p12 >> i, p11 >> i, ra, rb);
