@@ -6,7 +6,10 @@ prints ONE JSON line on rank 0.
 
   step      one pass of the hot path over one batch: one detexhipDecompressTextureLinearDevice
             call (= one kernel launch) decoding a whole block stream that is already resident in
-            HBM into a device-resident linear image.
+            HBM into a device-resident linear image.  Before the W warm-up and K timed steps the
+            same launch is repeated, untimed, until its duration has settled (`settle` in the
+            line; --no-settle starts cold): the first few hundred launches after idle run through
+            a power-management excursion that a steady decode stream never sees.
   N == 1    workload = BASELINE.json configs[1]: BC1 -> RGBA8, 8192 x 8192, synthetic stream U
             (splitmix64, tests/oracle_lib.py).  Extra keys: `per_format` (the six headline formats
             of configs[1..4] at 8192^2, streams U/M/C, plus the weakest kernels -- signed BC6H,
@@ -131,6 +134,7 @@ def main():
                     help="linear = detexDecompressTextureLinear (headline); tiled = detexDecompressTextureTiled (block-major output)")
     ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-settle", action="store_true", help="start the contract's W + K launches cold (no settling launches before them)")
     ap.add_argument("--no-extras", action="store_true", help="skip per_format / strong_image_32768 / weak / gather extras")
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is timed by default when N > 1)")
     ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
@@ -326,6 +330,12 @@ def main():
             log("bench.py: stream C needs a bundled fixture of", fmt.name)
             sys.exit(4)
     job = Job(fmt, W, H, data, args.layout, args.target)
+    # Before the contract's W + K launches: run the kernel until its launch time has settled (the same criterion as the per-format
+    # table).  The first ~250 launches after idle are not representative of a decode stream -- VALU-heavy kernels slow down for
+    # a few hundred launches while the power management reacts, and the `sc1 nt` row stores of round 3 show the same excursion
+    # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ... ) -- so a
+    # timed region of 20-200 launches right after start-up would measure the excursion, not the kernel.  --no-settle skips it.
+    settle_us, settle_launches = (None, 0) if args.no_settle else steady_state_us(job)
     wall, launch_ms = timed(job, args.steps, args.warmup)
     image_pixels = strong * strong if strong else world * W * H
     gpix = image_pixels * args.steps / wall / 1e9
@@ -446,6 +456,8 @@ def main():
                      "algorithmic_bytes_per_launch": job.alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
                      "write_frac": round(job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         "verified_bit_exact_rows": verified_rows,
+        "settle": {"launches_before_warmup": settle_launches, "last_window_us": None if settle_us is None else round(settle_us, 3),
+                   "note": "untimed launches before the W warm-up steps, until two 100-launch windows agree within 1.2 % and >= 600 ran (--no-settle: none)"},
     }
     if verified_rows == 0:
         log("bench.py: OUTPUT MISMATCH against the oracle")

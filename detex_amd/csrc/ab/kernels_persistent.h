@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_p
 			uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 			if (stores_enabled(o)) {
 #pragma unroll
-				for (int r = 0; r < 4; r++) store_row<ROW, true>(dst + (uint64_t)r * pitch, o + r * ROW);
+				for (int r = 0; r < 4; r++) store_row<ROW, 4>(dst + (uint64_t)r * pitch, o + r * ROW);
 			}
 			raise_status(!ok, status);
 		}

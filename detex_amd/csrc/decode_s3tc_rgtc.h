@@ -257,6 +257,7 @@ struct DecSignedRGTC1 {
 struct DecSignedRGTC2 {
 	static DH void prepare() { rgtc_signed_prepare(); }
 	static constexpr int kBlockBytes = 16, kPixelBytes = 4, kNative = kNatSignedRG16;
+	static constexpr int kStorePolicy = 4;		// plain `nt` row stores: `sc1 nt` costs this kernel 6-9 % (kernels.h: StorePolicy)
 	// decompress-rgtc.c:141-147: texel = R16 | G16 << 16
 	template <bool CHECKED> static DH bool decode(uint4 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {
 		uint32_t r[8], g[8];

@@ -181,30 +181,62 @@ template <class Dec, int EPI> DH void prepare_epilogue() {
 	if constexpr (NativeOf<Dec>::value == kNatFloatRGBX16 && EPI >= kEpiToRGBX8) half_lut_prepare();
 }
 
-// one 4-pixel row of ROW dwords; non-temporal (streaming) or ordinary stores
-template <int ROW, bool NT> DH void store_row(uint8_t *dst, const uint32_t *d) {
+// A streaming store of 4 / 8 / 12 / 16 bytes with cache policy POLICY: bit 0 = sc0, bit 1 = sc1, bit 2 = nt (gfx940+; sc0 / sc1 are
+// the coherence scope, nt the non-temporal hint).  __builtin_nontemporal_store emits `nt` alone (4).  Measured:
+// without nt the decode kernels lose a quarter (write-allocate in L2 beside the block stream); `sc1 nt` (6) beats plain `nt` by
+// 1.3-1.4 % for the kernels with 32-bit and narrower pixels at 8192^2 and 16384^2 and loses 2.7 % for the 64-bit pixels of BC6H.
+// (The compiler has no way to emit these policies, so the instruction is inline asm -- and inline asm is opaque to the hazard
+// recognizer: a VMEM store of more than 8 bytes reads its data registers up to two cycles AFTER it issues, and a VALU instruction
+// must not overwrite them in that window (gfx940: two wait states).  The register allocator reuses a row's registers for the next
+// row's address at once: without the s_nop behind the store a tenth of the first texel rows of BC7 blocks carried eight bytes of
+// pointer, differently on every run; tests/test_gpu_host_multi.py caught it.)
+template <int POLICY, int DWORDS, class V, class P> DH void store_with_policy(V v, P *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(DWORDS >= 1 && DWORDS <= 4, "dword .. dwordx4");
+	if constexpr (POLICY == 4) __builtin_nontemporal_store(v, p);
+	else if constexpr (POLICY == 0) *p = v;
+	else {
+#define DETEXHIP_STORE(BITS) \
+		if constexpr (DWORDS == 1) asm volatile("global_store_dword %0, %1, off " BITS :: "v"(p), "v"(v) : "memory"); \
+		else if constexpr (DWORDS == 2) asm volatile("global_store_dwordx2 %0, %1, off " BITS :: "v"(p), "v"(v) : "memory"); \
+		else if constexpr (DWORDS == 3) asm volatile("global_store_dwordx3 %0, %1, off " BITS "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); \
+		else asm volatile("global_store_dwordx4 %0, %1, off " BITS "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory")
+		if constexpr (POLICY == 1) { DETEXHIP_STORE("sc0"); }
+		else if constexpr (POLICY == 2) { DETEXHIP_STORE("sc1"); }
+		else if constexpr (POLICY == 3) { DETEXHIP_STORE("sc0 sc1"); }
+		else if constexpr (POLICY == 5) { DETEXHIP_STORE("sc0 nt"); }
+		else if constexpr (POLICY == 6) { DETEXHIP_STORE("sc1 nt"); }
+		else { DETEXHIP_STORE("sc0 sc1 nt"); }
+#undef DETEXHIP_STORE
+	}
+#else
+	*p = v;
+#endif
+}
+// cache policy of a decoder's stores: DEFAULT (tune.h) unless that is `sc1 nt` and the decoder is one of those the sweep found better
+// off with plain `nt` (Dec::kStorePolicy)
+template <class Dec, int DEFAULT, class = void> struct PolicyFor { static constexpr int value = DEFAULT; };
+template <class Dec, int DEFAULT> struct PolicyFor<Dec, DEFAULT, std::enable_if_t<(Dec::kStorePolicy >= 0)>> { static constexpr int value = DEFAULT == 6 ? Dec::kStorePolicy : DEFAULT; };
+template <class Dec> using StorePolicy = PolicyFor<Dec, Tune::kStorePolicy>;
+// one 4-pixel row of ROW dwords with cache policy POLICY (0 = ordinary stores)
+template <int ROW, int POLICY> DH void store_row(uint8_t *dst, const uint32_t *d) {
 	if constexpr (ROW == 1) {
-		if (NT) __builtin_nontemporal_store(d[0], reinterpret_cast<uint32_t *>(dst));
-		else *reinterpret_cast<uint32_t *>(dst) = d[0];
+		store_with_policy<POLICY, 1>(d[0], reinterpret_cast<uint32_t *>(dst));
 	} else if constexpr (ROW == 2) {
 		typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-		v2 v = { d[0], d[1] };
-		if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2 *>(dst));
-		else *reinterpret_cast<v2 *>(dst) = v;
+		store_with_policy<POLICY, 2>(v2{ d[0], d[1] }, reinterpret_cast<v2 *>(dst));
 	} else if constexpr (ROW == 3) {
 		typedef uint32_t v3 __attribute__((ext_vector_type(3)));
 		typedef v3 v3_unaligned __attribute__((aligned(4)));
-		v3 v = { d[0], d[1], d[2] };
-		if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v3_unaligned *>(dst));
-		else *reinterpret_cast<v3_unaligned *>(dst) = v;
+		// (only dword-aligned; the alignment of the pointee type matters to the plain and builtin forms, not to the instruction)
+		if constexpr (POLICY == 4) __builtin_nontemporal_store(v3{ d[0], d[1], d[2] }, reinterpret_cast<v3_unaligned *>(dst));
+		else if constexpr (POLICY == 0) *reinterpret_cast<v3_unaligned *>(dst) = v3{ d[0], d[1], d[2] };
+		else store_with_policy<POLICY, 3>(v3{ d[0], d[1], d[2] }, reinterpret_cast<v3 *>(dst));
 	} else {
 		typedef uint32_t v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-		for (int k = 0; k < ROW / 4; k++) {
-			v4 v = { d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] };
-			if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(dst) + k);
-			else reinterpret_cast<v4 *>(dst)[k] = v;
-		}
+		for (int k = 0; k < ROW / 4; k++)
+			store_with_policy<POLICY, 4>(v4{ d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }, reinterpret_cast<v4 *>(dst) + k);
 	}
 }
 
@@ -297,9 +329,9 @@ struct WideRowStore {
 		const v4 a = slab[src_a], b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		if (store_a) __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst_a));
+		if (store_a) store_with_policy<Tune::kStorePolicyWide, 4>(a, reinterpret_cast<v4 *>(dst_a));
 		store_pause();
-		if (store_b) __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst_b));
+		if (store_b) store_with_policy<Tune::kStorePolicyWide, 4>(b, reinterpret_cast<v4 *>(dst_b));
 		store_pause();
 		dst_a += pitch; dst_b += pitch;			// (one 64-bit add each; r * pitch came out as two v_mad_u64_u32 per pointer)
 	}
@@ -418,7 +450,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		uint8_t *dst = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * (4u * ROW);
 		if (stores_enabled(o)) {
 #pragma unroll
-			for (int r = 0; r < 4; r++) { store_row<ROW, NT>(dst + (uint64_t)r * pitch, o + r * ROW); store_pause(); }
+			for (int r = 0; r < 4; r++) { store_row<ROW, (NT ? StorePolicy<Dec>::value : 0)>(dst + (uint64_t)r * pitch, o + r * ROW); store_pause(); }
 		}
 		raise_status(!ok, status);
 	}
@@ -549,7 +581,7 @@ __global__ __launch_bounds__(256) void decode_linear_grouped(const void *__restr
 			for (int g = 0; g < G; g++)
 #pragma unroll
 				for (int k = 0; k < ROW; k++) row[g * ROW + k] = o[g][r * ROW + k];
-			store_row<ROW * G, NT>(dst + (uint64_t)r * pitch, row);
+			store_row<ROW * G, (NT ? StorePolicy<Dec>::value : 0)>(dst + (uint64_t)r * pitch, row);
 		}
 	}
 	raise_status(!ok, status);
@@ -621,7 +653,7 @@ void decode_blocks(const void *__restrict__ blocks,
 			if (!live) return;
 			uint32_t o[4];
 			const bool ok = decode_block<Dec, EPI, CHECKED>(blocks, i, mode_mask, flags, o);
-			__builtin_nontemporal_store(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
+			store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(v4{ o[0], o[1], o[2], o[3] }, reinterpret_cast<v4 *>(pixels) + i);
 			if (ok_out) ok_out[i] = ok ? 1 : 0;
 			raise_status(!ok, status);
 		} else {
@@ -673,7 +705,7 @@ void decode_blocks(const void *__restrict__ blocks,
 				for (int j = 0; j < GROUP * ROW / 64; j++) {
 					const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
 					const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
-					if (g < vectors) __builtin_nontemporal_store(*slot(e % ROW, e / ROW), out + g);
+					if (g < vectors) store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(*slot(e % ROW, e / ROW), out + g);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();

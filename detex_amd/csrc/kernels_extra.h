@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
 	if (lv.fast) {
 #pragma unroll
-		for (int r = 0; r < 4; r++) store_row<ROW, true>(dst + (uint64_t)r * lv.pitch, o + r * ROW);
+		for (int r = 0; r < 4; r++) store_row<ROW, 4>(dst + (uint64_t)r * lv.pitch, o + r * ROW);
 	} else {
 #pragma unroll
 		for (int r = 0; r < 4; r++) {

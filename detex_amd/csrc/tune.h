@@ -30,6 +30,11 @@ struct ProductTune {
 	static constexpr int kWorkgroupsPerCu = -1;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate?
 	static constexpr int kStoreSleep = 0;
+	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store
+	// emits): pixels of up to 32 bits / the 64-bit pixels of BC6H (kernels.h: store_with_policy)
+	static constexpr int kStorePolicy = 6;
+	static constexpr int kStorePolicyWide = 4;
+	static constexpr int kStorePolicyBlocks = 6;	// the block-major kernels' 16-byte stores
 	// v_bitop3_b32 masks pinned into VGPRs (an SGPR source halves the issue rate of a full-rate VALU op)
 	static constexpr bool kMasksInVgprs = true;
 	// RGTC1: blocks per lane in the linear kernel

@@ -9,6 +9,8 @@
 #   grpN                    BC7: subset rows requested together in the per-record copies
 #   bc7stage                block-major BC7 with the separate 17 KiB staging array
 #   bc6wavesN               BC6H register budget (waves per SIMD)
+#   policyN / widepolicyN / blockspolicyN   cache policy of the linear kernels' row stores, pixels up to 32 bits / 64-bit pixels, and of the block-major kernels' stores: bit 0 sc0, bit 1 sc1,
+#                           bit 2 nt (product: 6 = sc1 nt / 4 = nt)
 #   rowwise                 BC6H linear kernel: texel rows exchanged and stored as the decoder completes them
 #   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
 #   sgprconst               v_bitop3 masks left in SGPRs
@@ -36,6 +38,9 @@ for v in "$@"; do
       plain) body+="static constexpr bool kBc7Uniform = false; " ;;
       bc7stage) body+="static constexpr bool kBc7OwnStage = false; " ;;
       prio*) body+="static constexpr int kBc7Prio = ${k#prio}; " ;;
+      blockspolicy*) body+="static constexpr int kStorePolicyBlocks = ${k#blockspolicy}; " ;;
+      widepolicy*) body+="static constexpr int kStorePolicyWide = ${k#widepolicy}; " ;;
+      policy*) body+="static constexpr int kStorePolicy = ${k#policy}; " ;;
       rowwise) body+="static constexpr bool kRowWise = true; " ;;
       bc6waves*) body+="static constexpr int kBc6hWavesPerSimd = ${k#bc6waves}; " ;;
       bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;

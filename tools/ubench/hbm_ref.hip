@@ -117,6 +117,39 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill(void *dst, siz
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// the fill of fill_kernel (pattern 2) with an explicit cache policy on the store: POLICY bit 0 = sc0, bit 1 = sc1, bit 2 = nt
+// (gfx940+: sc0 / sc1 give the coherence scope, nt the non-temporal hint; __builtin_nontemporal_store emits `nt` alone = 4)
+template <int POLICY> __global__ __launch_bounds__(256) void fill_policy_kernel(v4 *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint64_t base = (uint64_t)blockIdx.x * 1024u;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint64_t i = base + (uint64_t)r * 256u + threadIdx.x;
+		if (i < n_vectors) {
+			const v4 v = make_vector<2>((uint32_t)i, seed);
+			v4 *p = dst + i;
+			if constexpr (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(v) : "memory");
+			else if constexpr (POLICY == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+			else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+		}
+	}
+}
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_policy(void *dst, size_t bytes, int policy, uint32_t seed, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const dim3 grid((unsigned)((n + 1023u) / 1024u)), block(256);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+#define POL(P) case P: hipLaunchKernelGGL((fill_policy_kernel<P>), grid, block, 0, s, d, n, seed); break;
+	switch (policy) { POL(0) POL(1) POL(2) POL(3) POL(4) POL(5) POL(6) POL(7) default: return 1; }
+#undef POL
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" __attribute__((visibility("default"))) int hbmref_copy(void *dst, const void *src, size_t bytes, int nontemporal, void *stream) {
 	const uint64_t n = bytes / 16u;
 	if (n == 0 || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u)) return 1;
