@@ -9,8 +9,8 @@
 //          (R<->B swizzle, RGBX8 -> packed RGB8) -- free at HBM rate, no second pass over the image
 //   store  linear layout: texel row r of the 64 blocks is 64 x 4T contiguous bytes of image
 //          row 4*by+r (T = bytes per target pixel)  ->  four (T=8: eight) wave-wide
-//          non-temporal stores, each a single 0.75-2 KiB contiguous run (full 128 B lines,
-//          no partial-line writes, no read-for-ownership)
+//          non-temporal stores (cache policy `sc1 nt`, or `nt` where that measured better: store_with_policy),
+//          each a single 0.75-2 KiB contiguous run (full 128 B lines, no partial-line writes, no read-for-ownership)
 //          tiled layout: a lane's block is 16*T contiguous bytes and the wave's 64 blocks are
 //          contiguous too, so they are staged in LDS in output order and leave as T/1 wave-wide
 //          1 KiB-run stores as well (decode_blocks)
