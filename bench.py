@@ -242,22 +242,29 @@ def main():
             wall, ev_ms = t.tolist()
         return wall, ev_ms / steps
 
-    def steady_state_us(job, window=100, max_windows=16, tol=0.012, min_launches=600):
-        """launch time once the power-management transient of VALU-heavy kernels has passed (DESIGN.md section 6:
-        20-40 % slower for launches ~25-300, then a slow approach to the settled clock): windows of `window` launches
-        until two consecutive ones agree within `tol` and at least `min_launches` have run; independent of the driver's
-        --steps / --warmup.  (Round 2's first tables used 3 % / 400 launches and read VALU-heavy kernels up to 8 % high.)"""
-        prev, done, us = None, 0, None
-        for _ in range(max_windows):
+    def steady_state_us(job, window=100, max_windows=16, tol=0.012, min_launches=600, min_ms=40.0):
+        """launch time once the power-management excursion has passed (20-40 % slower for roughly the 2nd to
+        12th millisecond after idle -- VALU-heavy kernels and, since round 3, every kernel with `sc1 nt` stores -- then a slow approach
+        to the settled clock): windows of launches (>= `window` of them and >= 4 ms each) until two consecutive ones agree within
+        `tol` and at least `min_launches` launches and `min_ms` of kernel time have gone by; independent of the driver's --steps /
+        --warmup.  (Round 2's first tables used 3 % / 400 launches and read VALU-heavy kernels up to 8 % high; a launch-count-only
+        criterion let the 13 us RGTC1 kernel stop after 8 ms, in the middle of the excursion.)"""
+        prev, done, us, spent_ms = None, 0, None, 0.0
+        for _ in range(4 * max_windows):
+            n = window if us is None else max(window, int(4000.0 / us) + 1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(window):
+            for _ in range(n):
                 job.step()
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / window * 1e3
-            done += window
-            if prev is not None and done >= min_launches and abs(us - prev) <= tol * prev:
+            ms = e0.elapsed_time(e1)
+            us = ms / n * 1e3
+            done += n
+            spent_ms += ms
+            if prev is not None and done >= min_launches and spent_ms >= min_ms and abs(us - prev) <= tol * prev:
+                break
+            if spent_ms > 400.0:
                 break
             prev = us
         return us, done

@@ -80,15 +80,18 @@ for fname in args.formats.split(","):
                 if args.clocks:
                     t = threading.Thread(target=poll_clocks, args=(stop, samples)); t.start()
                 window = 100 if alg < 1.5e9 else 25
-                prev, done, us = None, 0, None
-                for _ in range(14):
+                prev, done, us, spent_ms = None, 0, None, 0.0
+                for _ in range(40):
+                    n = window if us is None else max(window, int(4000.0 / us) + 1)     # windows of >= 4 ms
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(window):
+                    for _ in range(n):
                         step()
                     e1.record(); torch.cuda.synchronize()
-                    us = e0.elapsed_time(e1) / window * 1e3; done += window
-                    if prev is not None and done >= 6 * window and abs(us - prev) <= 0.012 * prev:
+                    ms = e0.elapsed_time(e1); us = ms / n * 1e3; done += n; spent_ms += ms
+                    if prev is not None and done >= 6 * window and spent_ms >= 40.0 and abs(us - prev) <= 0.012 * prev:
+                        break
+                    if spent_ms > 400.0:
                         break
                     prev = us
                 if args.clocks:
