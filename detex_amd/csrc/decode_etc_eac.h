@@ -392,7 +392,6 @@ struct DecETC1 {
 };
 struct DecETC2 {
 	static constexpr int kBlockBytes = 8, kPixelBytes = 4;
-	static constexpr int kStorePolicy = 4;		// plain `nt` row stores: `sc1 nt` is neutral on random blocks, +0.9 % on the fixture
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t mode_mask, uint32_t flags, uint32_t (&d)[16]) {
 		return etc_colour<1, 0xFF000000u, CHECKED>(blk.x, blk.y, mode_mask, flags, d);
 	}

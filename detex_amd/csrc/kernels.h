@@ -184,7 +184,7 @@ template <class Dec, int EPI> DH void prepare_epilogue() {
 // A streaming store of 4 / 8 / 12 / 16 bytes with cache policy POLICY: bit 0 = sc0, bit 1 = sc1, bit 2 = nt (gfx940+; sc0 / sc1 are
 // the coherence scope, nt the non-temporal hint).  __builtin_nontemporal_store emits `nt` alone (4).  Measured:
 // without nt the decode kernels lose a quarter (write-allocate in L2 beside the block stream); `sc1 nt` (6) beats plain `nt` by
-// 1.3-1.4 % for the kernels with 32-bit and narrower pixels at 8192^2 and 16384^2 and loses 2.7 % for the 64-bit pixels of BC6H.
+// 1-3 % (RGTC1: 15 %) for the kernels with 32-bit and narrower pixels at 8192^2 and 16384^2 and loses 2.7 % for the 64-bit pixels of BC6H.
 // (The compiler has no way to emit these policies, so the instruction is inline asm -- and inline asm is opaque to the hazard
 // recognizer: a VMEM store of more than 8 bytes reads its data registers up to two cycles AFTER it issues, and a VALU instruction
 // must not overwrite them in that window (gfx940: two wait states).  The register allocator reuses a row's registers for the next
