@@ -278,16 +278,18 @@ struct FormatEntry {
 // and BC6H lose (their staging already takes the LDS of several workgroups) and keep what fits.
 // (Re-swept with the `sc1 nt` row stores at the end of round 3, profiles/r03/explore_r03i/wg_sweep_sc1nt.jsonl: the table stands except for
 // EAC_R11 / EAC_SIGNED_R11, which had six and now run best uncapped: 23.2 -> 22.7 us, on the fixture 22.5 -> 21.6, and ETC2, which takes
-// `sc1 nt` only together with six instead of five: 42.3 / 42.0 -> 41.8 / 40.6.)
+// `sc1 nt` only together with six instead of five: 42.3 / 42.0 -> 41.8 / 40.6.  Block-major, same re-sweep (tiled_resident_sc1nt.jsonl): the ETC
+// family at seven per CU (ETC2 43.4 / 41.8 -> 42.0 / 40.8, ETC1, punchthrough and ETC2_EAC 1.3-1.7 %), BC6H at four: its fixture 91.7 -> 81.5 us
+// at the price of 85.0 -> 89.0 on random blocks -- the same trade as in the linear kernel.)
 const FormatEntry kFormats[20] = {
 	{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 },
 	FMT(BC1, DecBC1, kClassS3TC, 5, 5), FMT(BC1A, DecBC1A, kClassS3TC, 5, 5), FMT(BC2, DecBC2, kClassS3TCat8, 5, 5), FMT(BC3, DecBC3, kClassS3TCat8, 5, 5),
 	FMT(RGTC1, DecRGTC1, kClassNone, 0, 0), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone, 0, 0), FMT(RGTC2, DecRGTC2, kClassNone, 6, 0),
 	FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone, 5, 5),
-	FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 0), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
+	FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 4), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
 	FMT(BPTC, DecBPTC, kClassBPTC, 0, 0),
-	FMT(ETC1, DecETC1, kClassETC1, 5, 5), FMT(ETC2, DecETC2, kClassETC2, 6, 0), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough, kClassETC2PT, 6, 0),
-	FMT(ETC2_EAC, DecETC2EAC, kClassETC2at8, 0, 0),
+	FMT(ETC1, DecETC1, kClassETC1, 5, 7), FMT(ETC2, DecETC2, kClassETC2, 6, 7), FMT(ETC2_PUNCHTHROUGH, DecETC2Punchthrough, kClassETC2PT, 6, 7),
+	FMT(ETC2_EAC, DecETC2EAC, kClassETC2at8, 0, 7),
 	FMT(EAC_R11, DecEACR11, kClassNone, 0, 0), FMT(EAC_SIGNED_R11, DecEACSignedR11, kClassNone, 0, 0), FMT(EAC_RG11, DecEACRG11, kClassNone, 5, 5),
 	FMT(EAC_SIGNED_RG11, DecEACSignedRG11, kClassNone, 5, 5),
 };
