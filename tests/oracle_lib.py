@@ -199,10 +199,11 @@ STREAM_SEED_BASE = 0xD37E5000
 STREAM_SEED_K = {"BC1": 0, "BC3": 1, "BPTC": 2, "ETC2": 3, "ETC2_EAC": 4, "BPTC_FLOAT": 5}
 
 
-def splitmix64_words(seed, n):
-    """n little-endian u64 words of splitmix64 (vectorised, identical to the scalar recurrence)."""
+def splitmix64_words(seed, n, first=0):
+    """words [first, first + n) of the splitmix64 stream as little-endian u64 (vectorised, identical to the scalar recurrence:
+    word k depends on k only, so any slice of a stream is computed without the words before it)."""
     with np.errstate(over="ignore"):
-        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64))
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(first + 1, first + n + 1, dtype=np.uint64))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
@@ -214,6 +215,15 @@ def stream_u(fmt, n_blocks, seed=None):
     if seed is None:
         seed = STREAM_SEED_BASE + STREAM_SEED_K.get(fmt.name, 16 + fmt.index)
     return splitmix64_words(seed, n_blocks * fmt.block_bytes // 8).view(np.uint8)
+
+
+def stream_u_slice(fmt, first_block, n_blocks, seed=None):
+    """blocks [first_block, first_block + n_blocks) of stream U: what a rank that owns a band of a sharded image materialises
+    (detex_amd/sharding.py: shard_of(...).in_offset / in_bytes), identical to the same slice of stream_u(fmt, total)"""
+    if seed is None:
+        seed = STREAM_SEED_BASE + STREAM_SEED_K.get(fmt.name, 16 + fmt.index)
+    wpb = fmt.block_bytes // 8
+    return splitmix64_words(seed, n_blocks * wpb, first_block * wpb).view(np.uint8)
 
 
 def fnv1a64(buf):

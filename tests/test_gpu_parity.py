@@ -500,21 +500,26 @@ def test_signed_bc6h_extreme_magnitudes(torch_cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), want_l)
 
 
-@pytest.mark.parametrize("name,W,H", [("BC1", 32768, 8192), ("BPTC_FLOAT", 32768, 4096)])
-def test_sharded_config_bands_whole_digest(name, W, H, torch_cuda, golden_json):
-    """one GPU's band of the sharded 32768^2 configurations (BASELINE configs[4] / north_star: BC1 over 4 GPUs, BC6H over
-    8): sha256 of the WHOLE band (1 GiB of pixels) against the compiled reference's (tools/make_goldens.py bands)"""
-    from detex_amd import binding
+@pytest.mark.parametrize("name,world,g", [("BC1", 4, g) for g in range(4)] + [("BPTC_FLOAT", 8, g) for g in range(8)] + [("BC1", 8, 5)])
+def test_sharded_config_bands_whole_digest(name, world, g, torch_cuda, golden_json):
+    """EVERY band of the sharded 32768^2 configurations (BASELINE configs[4] / north_star: BC1 over 4 GPUs, BC6H over 8;
+    texture.c:105-145 on those inputs): rank g's launch exactly as bench.py --gpus N issues it -- the band's blocks from the
+    GLOBAL stream offset (sharding.shard_of -> stream_u_slice), one detexhipDecompressTextureLinearDevice call over the band --
+    and the sha256 of the WHOLE band (1 GiB of pixels) against the compiled reference's (tools/make_goldens.py bands_all)"""
+    from detex_amd import binding, sharding
     torch = torch_cuda
     fmt = F.BY_NAME[name]
-    g = golden_json("digests_8192.json")["bands"]["%s/%dx%d" % (name, W, H)]
-    data = ol.stream_u(fmt, (W // 4) * (H // 4))
-    assert sha(data) == g["in_sha256"]
+    side = 32768
+    gold = golden_json("digests_8192.json")["bands_all"]["%s/%d/%dof%d" % (name, side, g, world)]
+    sh = sharding.shard_of(g, world, fmt, side, side)
+    assert (sh.row0, sh.row1) == (gold["row0"], gold["row1"])
+    data = ol.stream_u_slice(fmt, sh.in_offset // fmt.block_bytes, sh.in_bytes // fmt.block_bytes)
+    assert sha(data) == gold["in_sha256"]
     status = torch.zeros(1, dtype=torch.int32, device="cuda")
-    out = binding.decompress_linear_device(fmt, _dev(torch, data), W, H, status=status)
+    out = binding.decompress_linear_device(fmt, _dev(torch, data), side, sh.px_rows, status=status)
     torch.cuda.synchronize()
-    assert out.numel() == g["bytes"] and bool(status.item() == 0) == g["ok"]
-    assert sha(out.cpu().numpy()) == g["sha256"]
+    assert out.numel() == gold["bytes"] == sh.out_bytes and bool(status.item() == 0) == gold["ok"]
+    assert sha(out.cpu().numpy()) == gold["sha256"]
     del out
     torch.cuda.empty_cache()
 

@@ -12,9 +12,10 @@ What it writes is data only -- inputs and the reference's outputs:
   tests/golden/clip.npz             clipped (width/height not multiples of 4) linear decodes
   tests/golden/digests_8192.json    sha256 (+ FNV-1a-64) of the reference output on the 8192x8192 streams U (all formats),
                                     M (BPTC, BPTC_FLOAT) and C (every format with a fixture), on converted targets, and on
-                                    whole 32768-wide bands of the sharded configs
+                                    whole 32768-wide bands of the sharded configs ("bands": the first band of each; "bands_all": every band
+                                    of BC1 32768^2 over 4 ranks and BPTC_FLOAT 32768^2 over 8, from the global stream offsets)
                                     ("clipped": large textures whose width / height are not multiples of four)
-usage: python tools/make_goldens.py [fixtures] [vectors] [digests] [digests_c] [digests_pf] [bands] [clipped]   (default: all)
+usage: python tools/make_goldens.py [fixtures] [vectors] [digests] [digests_c] [digests_pf] [bands] [bands_all] [clipped]   (default: all)
 """
 import ctypes, hashlib, json, os, shutil, sys, time
 import numpy as np
@@ -51,7 +52,7 @@ def ref_linear_mt(ref, f, data, W, H, pf=None, threads=None):
 
 
 def main():
-    sections = set(sys.argv[1:]) or {"fixtures", "vectors", "digests", "digests_c", "digests_pf", "bands", "clipped"}
+    sections = set(sys.argv[1:]) or {"fixtures", "vectors", "digests", "digests_c", "digests_pf", "bands", "bands_all", "clipped"}
     os.makedirs(G, exist_ok=True)
     ref = ol.load_ref(); orc = ol.Oracle()
     orc.lib.orc_fnv1a64.restype = ctypes.c_uint64
@@ -105,6 +106,23 @@ def main():
             t = time.time(); ok, out = ref_linear_mt(ref, f, data, bw, bh); dt = time.time() - t
             dg["bands"]["%s/%dx%d" % (name, bw, bh)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size)}
             print(name, bw, bh, ok, "%.1fs" % dt, flush=True)
+    if "bands_all" in sections:
+        # EVERY band of the two sharded 32768^2 images (BASELINE configs[4] / north_star: BC1 over 4 GPUs, BC6H over 8), generated with
+        # the GLOBAL stream offsets a rank uses (sharding.shard_of -> ol.stream_u_slice): band g of G is what rank g of G decodes
+        from detex_amd import sharding
+        dg["bands_all"] = {}
+        # (BC1 also in eighths: a rank of bench.py --gpus N, N in 1, 2, 4, 8, checks the 8 / N eighths its band consists of)
+        for name, side, world in (("BC1", 32768, 4), ("BC1", 32768, 8), ("BPTC_FLOAT", 32768, 8)):
+            f = F.BY_NAME[name]
+            for g in range(world):
+                sh = sharding.shard_of(g, world, f, side, side)
+                data = ol.stream_u_slice(f, sh.row0 * (side // 4), (sh.row1 - sh.row0) * (side // 4))
+                t = time.time(); ok, out = ref_linear_mt(ref, f, data, side, sh.px_rows); dt = time.time() - t
+                assert out.size == sh.out_bytes
+                dg["bands_all"]["%s/%d/%dof%d" % (name, side, g, world)] = {"ok": ok, "sha256": sha(out), "in_sha256": sha(data), "bytes": int(out.size),
+                                                                           "row0": sh.row0, "row1": sh.row1}
+                print("band", name, g, world, ok, "%.1fs" % dt, flush=True)
+                del out
     if "clipped" in sections:
         # large textures with clipped last block column / row (texture.c:116-120, 132-136): interior through the throughput
         # kernel (aligned and dword-aligned rows), edge strips pixel by pixel, and widths whose rows are not even dword-aligned
