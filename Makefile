@@ -1,5 +1,5 @@
 # Top-level build: the product library (hipcc, gfx950) and the test-only oracle.
-#   make            -> detex_amd/lib/libdetexhip.so  +  oracle/ checkers
+#   make -j         -> detex_amd/lib/libdetexhip.so  +  oracle/ checkers
 #   make lib        -> only the product library
 #   make ubench     -> tools/ubench/valu_rates (instruction-rate micro-benchmark) and tools/ubench/libhbmref.so (HBM fill / copy
 #                      reference kernels of bench.py); measurement tools, not product
@@ -20,22 +20,43 @@ hbmref: tools/ubench/libhbmref.so
 tools/ubench/libhbmref.so: tools/ubench/hbm_ref.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -o $@ $<
 
-$(LIB): $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp $(HDRS)
-	@mkdir -p detex_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
-		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp
+# The library's translation units (detex_amd/csrc/host_internal.h lists what each one holds).  Only the .hip files contain device code:
+# one per format family plus the histogram kernels, compiled in parallel (make -j); the .cpp files are host code built by the same driver.
+SRCS_HIP := formats_s3tc_rgtc formats_etc_eac formats_bptc formats_bptc_float histogram
+SRCS_CPP := errors device_tier host_tier multi_device ktx_loader
+OBJDIR   := build/obj
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-pass-failed $(EXTRA_HIPFLAGS)
+OBJS     := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(SRCS_HIP) $(SRCS_CPP)))
 
-# measurement build with the rejected A/B kernels of DESIGN.md section 5 (DETEXHIP_LIB=$(LIB_AB) bench.py --variant N)
-lib-ab: $(LIB_AB)
-$(LIB_AB): $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp $(HDRS)
-	@mkdir -p build/explib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DDETEXHIP_AB_VARIANTS \
-		-Wall -Wno-unused-function -o $@ $(CSRC)/detexhip.hip $(CSRC)/ktx_loader.cpp
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $(LIB))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+# measurement build with the rejected A/B kernels (profiles/AB_RECORD.md; DETEXHIP_LIB=$(LIB_AB) bench.py --variant N)
+lib-ab:
+	$(MAKE) lib LIB=$(LIB_AB) OBJDIR=build/obj_ab EXTRA_HIPFLAGS=-DDETEXHIP_AB_VARIANTS
+
+# the library's host code under AddressSanitizer + UndefinedBehaviorSanitizer with a main that calls every entry point with hostile
+# arguments (tests/test_sanitized_host.py); host code only is instrumented (-fno-gpu-sanitize)
+SANFLAGS := -O1 -g -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=all
+api-san:
+	$(MAKE) tests/host_san/api_san OBJDIR=build/obj_san EXTRA_HIPFLAGS="$(SANFLAGS)"
+$(OBJDIR)/api_san_main.o: tests/host_san/api_san_main.cpp include/detex.h include/detexhip.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+tests/host_san/api_san: $(OBJDIR)/api_san_main.o $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -o $@ $^
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(LIB) $(LIB_AB) tools/ubench/valu_rates tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san tools/ubench/valu_rates tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib lib-ab oracle ubench hbmref clean
+.PHONY: all lib lib-ab api-san oracle ubench hbmref clean

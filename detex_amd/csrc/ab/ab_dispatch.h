@@ -1,4 +1,4 @@
-// ab/ab_dispatch.h -- launch-side selection of the rejected A/B kernels.
+// ab/ab_dispatch.h -- launch-side selection of the rejected A/B kernels (profiles/AB_RECORD.md).
 // Only compiled with -DDETEXHIP_AB_VARIANTS (make lib-ab); the product library contains none of this.
 //   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)           [BC1 only]
 //   2  default mapping with ordinary (cached) row stores
@@ -7,9 +7,13 @@
 //   5  BPTC with mode-sorted waves (workgroup counting sort by mode)
 //   6  persistent grid, twice as many workgroups as are resident at once (kernels_persistent.h)      [32-bit pixels]
 //   7  persistent grid, exactly the resident count
-// Included by detexhip.hip inside its anonymous namespace, after Geometry / PlainDecoder (the kernel headers
-// variant_tile4x4.h, decode_bptc_r01.h and kernels_sorted.h are included at file scope before it).
+// Included by launchers.h (after Geometry / PlainDecoder); the per-decoder hooks are ab_traits.h's templates, specialised by the
+// formats_*.hip translation unit that owns the decoder.
 #pragma once
+#include "ab_traits.h"
+#include "kernels_persistent.h"
+
+namespace detexhip {
 
 // workgroups of `kernel` that are resident at once on the current device
 template <class K> uint32_t resident_workgroups(K kernel) {
@@ -19,12 +23,6 @@ template <class K> uint32_t resident_workgroups(K kernel) {
 		return 2048;
 	return (uint32_t)per_cu * (uint32_t)cus;
 }
-
-template <class Dec> struct AltDecoder { using type = Dec; };
-template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };
-template <> struct AltDecoder<DecBPTC> { using type = r01::DecBPTCRegisterSelect; };
-template <class Dec> struct AltDecoder2 { using type = Dec; };
-template <> struct AltDecoder2<DecBPTC> { using type = r01::DecBPTCLdsFields; };
 
 // returns true if variant g.variant exists for <Dec, EPI> and was launched (*result = launch status)
 template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_t *result) {
@@ -58,8 +56,7 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 	}
 	if constexpr (ClassSorted<Dec>::kAvailable && EpilogueOf<Dec, EPI>::kRowDwords == 4) {
 		if (g.variant == 5) {
-			hipLaunchKernelGGL((decode_linear_sorted<Dec, EPI, true>), grid, block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status);
-			*result = hipGetLastError();
+			*result = ClassSorted<Dec>::template launch<EPI>(g.blocks, px, g.wb, n, g.pitch, g.status, g.stream);
 			return true;
 		}
 	}
@@ -74,3 +71,5 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 	}
 	return false;
 }
+
+}  // namespace detexhip

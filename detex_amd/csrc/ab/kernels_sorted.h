@@ -21,10 +21,13 @@
 #include "../kernels.h"
 #include "../decode_bptc.h"
 #include "decode_bptc_r01.h"
+#include "ab_traits.h"
 
 namespace detexhip {
 
-template <class Dec> struct ClassSorted { static constexpr bool kAvailable = false; };
+template <class Dec, int EPI, bool NT>
+__global__ void decode_linear_sorted(const void *__restrict__ blocks, uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks,
+		uint64_t pitch, uint32_t *__restrict__ status);
 
 template <> struct ClassSorted<DecBPTC> {
 	static constexpr bool kAvailable = true;
@@ -49,6 +52,10 @@ template <> struct ClassSorted<DecBPTC> {
 		}
 	}
 	typedef r01::DecBPTCRegisterFields Generic;			// straddling waves: all-modes decoder
+	template <int EPI> static hipError_t launch(const void *blocks, uint8_t *pixels, uint32_t wb, uint32_t n, uint64_t pitch, uint32_t *status, hipStream_t stream) {
+		hipLaunchKernelGGL((decode_linear_sorted<DecBPTC, EPI, true>), dim3((n + 255u) / 256u), dim3(256), 0, stream, blocks, pixels, wb, n, pitch, status);
+		return hipGetLastError();
+	}
 };
 
 template <class Dec, int EPI, bool NT>

@@ -3,8 +3,7 @@
 // BASELINE.json's north_star sketches "one wavefront owns a tile of 4x4 blocks, the compressed
 // blocks are staged into LDS with coalesced HBM loads, the 16 output texels are scattered with
 // wave-wide coalesced stores".  This file implements exactly that for BC1 so it can be timed
-// against the lane-per-block mapping of kernels.h (bench.py --variant 1; results in DESIGN.md
-// section 5).  Layout: workgroup = 4 waves = 4 horizontally adjacent tiles = 16x4 blocks;
+// against the lane-per-block mapping of kernels.h (bench.py --variant 1; results in profiles/AB_RECORD.md).  Layout: workgroup = 4 waves = 4 horizontally adjacent tiles = 16x4 blocks;
 // 64 threads stage the 64 blocks (4 rows x 128 contiguous bytes) into 512 B of LDS; then lane l
 // of wave w owns texel row (l >> 2) & 3 of block (4w + (l & 3), l >> 4): it re-reads its 8-byte
 // block from LDS (4 lanes broadcast-read the same address), rebuilds the palette and writes ONE
@@ -13,6 +12,7 @@
 #pragma once
 #include "../dev_common.h"
 #include "../decode_s3tc_rgtc.h"
+#include "ab_traits.h"
 
 namespace detexhip {
 
@@ -38,12 +38,6 @@ __global__ __launch_bounds__(256) void decode_linear_tile4x4_bc1(const uint2 *__
 	*reinterpret_cast<v4 *>(dst) = out;
 }
 
-template <class Dec> struct Tile4x4 {
-	static constexpr bool kAvailable = false;
-	static hipError_t launch(const void *, uint8_t *, uint32_t, uint32_t, uint64_t, uint32_t *, hipStream_t) {
-		return hipErrorNotSupported;
-	}
-};
 template <> struct Tile4x4<DecBC1> {
 	static constexpr bool kAvailable = true;
 	// BC1 has no invalid blocks, so the status word is never raised

@@ -3,17 +3,12 @@
 // 2 x u16 arithmetic helpers.  (Reference: bptc-tables.c:23-201, decompress-bptc.c:182-193.)
 #pragma once
 #include "dev_common.h"
+#include "path_types.h"
 #include "bptc_tables.inc"
 
 namespace detexhip {
 
-// Spec-conformance switches, carried in the upper bits of the decoders' `flags` argument (the reference's own flags are
-// bits 0-2, detex.h:397-411): the reference differs from the BPTC specification in two places, which
-// the decoders reproduce unless these are set (detexhipSetQuirks clears the corresponding quirk).
-enum : uint32_t {
-	kFlagSpecBc7Mode6PBit = 1u << 30,	// BC7 mode 6: the second endpoint's P-bit is read from block bit 64 (the reference reads 0)
-	kFlagSpecBc6hMode12Bit63 = 1u << 31,	// BC6H mode 12: block bit 63 (b0[11]) is used (the reference build drops it)
-};
+// (the spec-conformance switches kFlagSpec... carried in the decoders' `flags` are in path_types.h)
 
 // [0..63] two-subset partitions, [64..127] three-subset partitions; 2-bit subset field per texel
 __constant__ uint32_t kPartition2Bit[128] = { DETEXHIP_P2X_WORDS, DETEXHIP_P3_WORDS };

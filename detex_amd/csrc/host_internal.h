@@ -1,0 +1,100 @@
+// host_internal.h -- what the translation units of libdetexhip share on the host side (never installed; the public
+// interface is include/detex.h + include/detexhip.h).
+//
+//   errors.cpp               error convention (misc.c:73-94), the LUT data symbols the reference header's inline helpers name
+//   formats_s3tc_rgtc.hip    kernels + launchers of BC1/BC1A/BC2/BC3, RGTC1/2 +- signed     (decode_s3tc_rgtc.h)
+//   formats_etc_eac.hip      ... ETC1, ETC2, punchthrough, ETC2_EAC, EAC R11/RG11 +- signed  (decode_etc_eac.h)
+//   formats_bptc.hip         ... BPTC (BC7)                                                  (decode_bptc.h)
+//   formats_bptc_float.hip   ... BPTC_FLOAT / BPTC_SIGNED_FLOAT (BC6H), the half -> 8-bit table of their 8-bit epilogues
+//   histogram.hip            8f-4: mode histogram kernels and their entry points
+//   device_tier.cpp          format lookup, target pixel formats, per-thread settings, the detexhip*Device entry points
+//   host_tier.cpp            the reference's own entry points on host pointers (texture.c:55-145, the 19 leaf decoders)
+//   multi_device.cpp         one texture over several devices
+//   ktx_loader.cpp           8f-1
+// Only the .hip files contain device code; each instantiates the kernels of its formats and exports one row of launchers per
+// format (FormatEntry), which is all the host-only files know about the kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef DETEXHIP_BUILDING_LIBRARY
+#define DETEXHIP_BUILDING_LIBRARY 1
+#endif
+#include "../../include/detex.h"
+#include "../../include/detexhip.h"
+#include "path_types.h"
+
+#define HIP_TRY(expr, what)                                                                      \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) {                                                                  \
+			detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e_));     \
+			return false;                                                                        \
+		}                                                                                        \
+	} while (0)
+
+namespace detexhip {
+
+// ---- what a launcher is handed --------------------------------------------------------------------------------------------
+struct Geometry {
+	const void *blocks; void *pixels; uint32_t wb, hb, width, height; uint64_t pitch;
+	uint32_t *status; hipStream_t stream; int variant; int epi; uint32_t decode_flags;
+	int resident;		// workgroups per CU the linear kernel of this format runs best with (FormatEntry::resident; 0 = no cap)
+};
+struct BatchArgs {
+	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
+	hipStream_t stream; bool checked; int epi; int resident;
+};
+// one block handed over as a kernel argument (kernels_extra.h: decode_single)
+struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; };
+// 8f-3: all levels of a mip chain in one launch (kernels_extra.h: decode_levels)
+struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; uint32_t decode_flags; };
+
+// One row per block format (texture.c:27-48 is the reference's table of decompress functions): the launchers of its kernels.
+struct FormatEntry {
+	const char *name;
+	uint32_t texture_format;
+	hipError_t (*linear)(const Geometry &);
+	hipError_t (*blocks)(const BatchArgs &);
+	hipError_t (*single)(const SingleArgs &);
+	hipError_t (*levels)(LevelsArgs &);
+	int histogram_class;		// kClass... (histogram.hip)
+	const char *kernel_name;
+	int resident;			// resident workgroups per CU of the linear kernels (launchers.h: occupancy_cap_lds); 0 = whatever fits
+	int resident_blocks;		// the same for the block-major texture driver
+};
+// format index (texture_format >> 24, detex.h:913-915): 1-8, 9-10, 11, 12-19
+const FormatEntry *formats_s3tc_rgtc(), *formats_bptc_float(), *formats_bptc(), *formats_etc_eac();	// 8, 2, 1, 8 rows (formats_*.hip)
+const FormatEntry *lookup_format(uint32_t texture_format);		// nullptr: not a block format of this library (bounds-checked, SURVEY A-11)
+
+// ---- target pixel formats (device_tier.cpp) ----------------------------------------------------------------------------------
+int epilogue_for(uint32_t texture_format, uint32_t pixel_format);	// kEpi..., -1 = not offered
+bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format);
+// epilogue for an accepted pair with its device table in place on the CURRENT device (-2 + error message if the upload failed)
+int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format);
+hipError_t ensure_half_table();						// formats_bptc_float.hip
+uint8_t half_to_u8_entry(uint32_t half_bits);				// formats_bptc_float.hip (host function)
+bool stream_on_current_device(hipStream_t stream, const char *who);
+
+// ---- per-thread settings (device_tier.cpp): detexhipSetDevice / SetQuirks / SetKernelVariant ------------------------------------
+struct ThreadSettings { int device = -1, variant = -1, quirks = -1; };	// -1 = not read yet (environment / default)
+ThreadSettings &thread_settings();
+int current_variant();
+uint32_t current_spec_flags();						// the decoders' kFlagSpec... bits for the calling thread's quirk mask
+int max_variant();							// 0 in the product library
+
+// detexhipDecompressTextureLinearDevice with the quirk flags and kernel variant given explicitly instead of read from the calling
+// thread's settings: for worker threads that decode on behalf of a caller (multi_device.cpp)
+int linear_device_with(uint32_t texture_format, const void *d_blocks, int width, int height, int width_in_blocks, int height_in_blocks,
+	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant);
+
+// ---- 8f-4 (histogram.hip) ----------------------------------------------------------------------------------------------------------
+hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first);
+
+// ---- host tier <-> multi-device (host_tier.cpp, multi_device.cpp) --------------------------------------------------------------------
+void release_thread_context();
+void release_shard_slots();
+
+}  // namespace detexhip

@@ -1,0 +1,384 @@
+// host_tier.cpp -- the reference's own entry points on HOST pointers (include/detex.h): the texture drivers of texture.c:55-145, the
+// 19 leaf decoders of decompress-*.c and detexDecompressBlock, over the device tier.  There is NO CPU decode in this library:
+// every entry point, including the one-block leaf functions, runs the gfx950 kernels; without a usable HIP device the calls
+// fail with an error message.  Host code only.
+#include <cstdlib>
+#include <cstring>
+
+#include "host_internal.h"
+#include "tune.h"
+
+using namespace detexhip;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// per-thread device context of the host-pointer tier: a stream and grow-only device staging buffers that
+// detexhipReleaseThreadResources() hands back
+// ------------------------------------------------------------------------------------------------
+struct ThreadContext {
+	bool ready = false;
+	int device = -1;
+	hipStream_t stream = nullptr;
+	void *d_in = nullptr, *d_out = nullptr;
+	size_t in_cap = 0, out_cap = 0;
+	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls / histogram bins
+	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
+	uint8_t *h_pin = nullptr, *d_pin = nullptr;
+	size_t pin_cap = 0;
+	void release() {
+		if (!ready) return;
+		int prev = -1;
+		(void)hipGetDevice(&prev);
+		(void)hipSetDevice(device);
+		(void)hipStreamSynchronize(stream);
+		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
+		if (h_pin) (void)hipHostFree(h_pin);
+		(void)hipStreamDestroy(stream);
+		d_in = d_out = nullptr; d_status = nullptr; in_cap = out_cap = 0;
+		h_pin = d_pin = nullptr; pin_cap = 0;
+		stream = nullptr;
+		ready = false;
+		if (prev >= 0) (void)hipSetDevice(prev);
+	}
+	~ThreadContext() { release(); }
+};
+thread_local ThreadContext t_ctx;
+
+// The host tier always runs on the context's device, whatever device the calling thread has made current since
+// (e.g. torch.cuda.set_device): entry points hold one of these for their duration and the caller's device is
+// restored on return.
+struct DeviceScope {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceScope(int device) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != device) {
+			hipError_t e = hipSetDevice(device);
+			if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); ok = false; }
+		}
+	}
+	~DeviceScope() { int now = -1; if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev); }
+};
+
+bool context_ready() {
+	ThreadContext &c = t_ctx;
+	if (c.ready) return true;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		detexSetErrorMessage("libdetexhip: no usable HIP device (%s); this library has no CPU decode path",
+			e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+		return false;
+	}
+	if (c.device < 0) {
+		ThreadSettings &s = thread_settings();		// detexhipSetDevice, else DETEXHIP_DEVICE, else 0
+		if (s.device < 0) { const char *env = getenv("DETEXHIP_DEVICE"); s.device = env ? atoi(env) : 0; }
+		c.device = s.device;
+	}
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
+	HIP_TRY(hipMalloc(&c.d_status, 64), "hipMalloc(status)");
+	c.ready = true;
+	return true;
+}
+
+bool reserve(void **buf, size_t *cap, size_t need) {
+	if (need <= *cap) return true;
+	if (*buf) HIP_TRY(hipFree(*buf), "hipFree");
+	*buf = nullptr; *cap = 0;
+	const size_t rounded = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+	HIP_TRY(hipMalloc(buf, rounded), "hipMalloc(staging)");
+	*cap = rounded;
+	return true;
+}
+
+// Small calls of the host tier (the one-block leaf functions; textures up to Tune::kHostDirectBytes of blocks + pixels): the
+// blocks are placed in a pinned, device-visible host buffer and the kernel reads them from there and writes pixels, ok bytes
+// and the status word back into it -- ONE launch and one stream synchronisation instead of memset + upload + launch + two
+// downloads (five runtime calls that cost more than the kernel's PCIe traffic for a few KiB).  Layout of the buffer:
+// [status word, ok byte: 256 B][blocks, 256-byte aligned][pixels, 256-byte aligned].
+struct DirectExchange { uint8_t *h_base, *d_base; size_t in_off, out_off; };
+bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, DirectExchange *x) {
+	const size_t in_off = 256, out_off = in_off + ((in_bytes + 255) & ~(size_t)255), need = out_off + ((out_bytes + 255) & ~(size_t)255);
+	if (need > c.pin_cap) {
+		if (c.h_pin) HIP_TRY(hipHostFree(c.h_pin), "hipHostFree");
+		c.h_pin = c.d_pin = nullptr; c.pin_cap = 0;
+		const size_t rounded = (need + 65535) & ~(size_t)65535;
+		void *h = nullptr, *d = nullptr;
+		HIP_TRY(hipHostMalloc(&h, rounded, hipHostMallocMapped), "hipHostMalloc");
+		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); detexSetErrorMessage("libdetexhip: hipHostGetDevicePointer failed"); return false; }
+		c.h_pin = static_cast<uint8_t *>(h); c.d_pin = static_cast<uint8_t *>(d); c.pin_cap = rounded;
+	}
+	*x = DirectExchange{ c.h_pin, c.d_pin, in_off, out_off };
+	return true;
+}
+
+// shared by the 19 leaf functions and detexDecompressBlock: one block through the GPU.
+// Returns 1 = decoded, 0 = the decoder returned false, -1 = HIP/runtime failure (message set).
+int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags,
+		uint8_t *pixel_buffer, uint32_t pixel_format) {
+	if (!context_ready()) return -1;
+	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return -1;
+	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
+	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
+	DirectExchange x;
+	if (!direct_exchange(c, bs, out_bytes, &x)) return -1;
+	x.h_base[4] = 0;								// the ok byte
+	auto run = [&]() -> bool {
+		const int epi = prepared_epilogue(f->texture_format, pixel_format);
+		if (epi == -2) return false;
+		SingleArgs a{ bitstring, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi };
+		HIP_TRY(f->single(a), "kernel launch");
+		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		return true;
+	};
+	if (!run()) return -1;
+	if (!x.h_base[4]) return 0;
+	memcpy(pixel_buffer, x.h_base + x.out_off, out_bytes);
+	return 1;
+}
+
+}  // namespace
+
+namespace detexhip {
+void release_thread_context() { t_ctx.release(); }
+}
+
+extern "C" int detexhipSetDevice(int device) {
+	if (t_ctx.ready && t_ctx.device != device) {	// checked BEFORE touching the current device
+		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d) after this thread already used device %d "
+			"(detexhipReleaseThreadResources() first)", device, t_ctx.device);
+		return 1;
+	}
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+		detexSetErrorMessage("libdetexhip: detexhipSetDevice(%d): no such device (%d present)", device, count);
+		return 1;
+	}
+	thread_settings().device = device;
+	t_ctx.device = device;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference tier: host pointers (include/detex.h)
+// ------------------------------------------------------------------------------------------------
+#define LEAF(NAME)                                                                                          \
+	extern "C" bool detexDecompressBlock##NAME(const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags, \
+			uint8_t *pixel_buffer) {                                                                         \
+		return decode_one_block(lookup_format(DETEX_TEXTURE_FORMAT_##NAME), bitstring, mode_mask, flags,  \
+			pixel_buffer, DETEX_TEXTURE_FORMAT_##NAME & 0xFFFFu) == 1;                                       \
+	}
+LEAF(BC1) LEAF(BC1A) LEAF(BC2) LEAF(BC3) LEAF(RGTC1) LEAF(SIGNED_RGTC1) LEAF(RGTC2) LEAF(SIGNED_RGTC2)
+LEAF(BPTC_FLOAT) LEAF(BPTC_SIGNED_FLOAT) LEAF(BPTC) LEAF(ETC1) LEAF(ETC2) LEAF(ETC2_PUNCHTHROUGH) LEAF(ETC2_EAC)
+LEAF(EAC_R11) LEAF(EAC_SIGNED_R11) LEAF(EAC_RG11) LEAF(EAC_SIGNED_RG11)
+#undef LEAF
+
+// texture.c:55-70
+extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_format, uint32_t mode_mask, uint32_t flags,
+		uint8_t *pixel_buffer, uint32_t pixel_format) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) {
+		detexSetErrorMessage("detexDecompressBlock: 0x%08X is not a block-compressed format of this library", texture_format);
+		return false;
+	}
+	if (!pixel_format_accepted(texture_format, pixel_format)) {
+		detexSetErrorMessage("detexDecompressBlock: conversion of format 0x%08X to pixel format 0x%08X is outside the "
+			"block-decode path of libdetexhip", texture_format, pixel_format);
+		return false;
+	}
+	const int r = decode_one_block(f, bitstring, mode_mask, flags, pixel_buffer, pixel_format);
+	if (r == 0)	// same text as the reference (texture.c:63-64); HIP failures have set their own message
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture_format);
+	return r == 1;
+}
+
+// shared body of the two texture drivers (texture.c:77-98, 105-145)
+//
+// upload -> one launch -> download on the thread's stream.  The PCIe download of the pixels bounds this tier (8192^2
+// BC1: 256 MiB at the 56 GB/s pageable copies reach on the test box = 4.8 ms; upload 0.6 ms, kernel 0.04 ms: 5.4 ms).
+// A band pipeline (upload k+1 | kernel k | download k-1 on three streams, uploads from a helper thread because
+// hipMemcpyAsync on pageable memory blocks its caller) was built and measured: 5.40 vs 5.45 ms -- a download that
+// shares the link with an upload runs at 41-50 GB/s instead of 56 and every extra copy call costs 30-50 us
+// (tools/ubench/host_paths.hip) -- so it was not kept.
+static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format, bool tiled) {
+	const char *who = tiled ? "detexDecompressTextureTiled" : "detexDecompressTextureLinear";
+	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	if (texture->width < 0 || texture->height < 0 || texture->width_in_blocks < 0 || texture->height_in_blocks < 0) {
+		detexSetErrorMessage("%s: negative texture dimensions", who);
+		return false;
+	}
+	const size_t wb = (size_t)texture->width_in_blocks, hb = (size_t)texture->height_in_blocks;
+	const size_t width = (size_t)texture->width, height = (size_t)texture->height;
+	const size_t out_bytes = tiled ? wb * hb * 16u * px : width * height * px;
+	if (!detexFormatIsCompressed(texture->format)) {
+		if (tiled) { detexSetErrorMessage("detexDecompressTextureTiled: Cannot handle uncompressed texture format"); return false; }
+		// texture.c:108-111 hands uncompressed textures to detexConvertPixels; only its identity
+		// edge (convert.c:1087-1092) belongs to this path.
+		const uint32_t src = detexGetPixelFormat(texture->format);
+		const bool same8 = (src == DETEX_PIXEL_FORMAT_RGBA8 || src == DETEX_PIXEL_FORMAT_RGBX8) &&
+			(pixel_format == DETEX_PIXEL_FORMAT_RGBA8 || pixel_format == DETEX_PIXEL_FORMAT_RGBX8);
+		if (src == pixel_format || same8) { memcpy(pixel_buffer, texture->data, out_bytes); return true; }
+		detexSetErrorMessage("%s: pixel conversion 0x%08X -> 0x%08X is outside the block-decode path of libdetexhip", who, src, pixel_format);
+		return false;
+	}
+	const FormatEntry *f = lookup_format(texture->format);
+	if (!f || !pixel_format_accepted(texture->format, pixel_format)) {
+		// the reference fails every block here: all-zero image and false
+		memset(pixel_buffer, 0, out_bytes);
+		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who,
+			texture->format, pixel_format);
+		return false;
+	}
+	if (out_bytes == 0 || wb * hb == 0) return true;
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	const size_t bs = detexGetCompressedBlockSize(texture->format);
+	const size_t in_bytes = wb * hb * bs;
+	// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
+	// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
+	const size_t cov_w = tiled ? 0 : (width < 4u * wb ? width : 4u * wb), cov_h = tiled ? 0 : (height < 4u * hb ? height : 4u * hb);
+	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
+		// small texture: the kernel reads the blocks from, and writes pixels and status into, pinned host memory (direct_exchange)
+		DirectExchange x;
+		if (!direct_exchange(c, in_bytes, out_bytes, &x)) return false;
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
+		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
+		int rc;
+		if (tiled)
+			rc = detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st);
+		else
+			rc = detexhipDecompressTextureLinearDevice(texture->format, x.d_base + x.in_off, (int)width, (int)height, (int)wb, (int)hb, x.d_base + x.out_off,
+				width * px, pixel_format, c.stream, d_st);
+		if (rc != 0) return false;
+		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		const uint8_t *res = x.h_base + x.out_off;
+		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
+		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
+			detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+			return false;
+		}
+		return true;
+	}
+	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, out_bytes)) return false;
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);
+	uint32_t status = 0;
+	HIP_TRY(hipMemcpyAsync(d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	int rc;
+	if (tiled)
+		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, c.d_status);
+	else
+		rc = detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format,
+			c.stream, c.d_status);
+	if (rc != 0) return false;
+	if (tiled || (cov_w == width && cov_h == height)) {
+		HIP_TRY(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	} else if (cov_w > 0 && cov_h > 0) {
+		HIP_TRY(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)");
+	}
+	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	if (status != 0) {
+		// same text the reference leaves behind after a failed block (texture.c:63-64)
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+		return false;
+	}
+	return true;
+}
+
+// 8f-3 host tier: what a caller of detexLoadKTXFileWithMipmaps does level by level (one
+// detexDecompressTextureLinear per level), as one staging copy in, ONE launch, one copy out.
+extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *textures, int n_textures,
+		uint8_t *const *pixel_buffers, uint32_t pixel_format) {
+	const char *who = "detexhipDecompressTexturesLinear";
+	if (n_textures <= 0) return true;
+	if (n_textures > kMaxLevels) { detexSetErrorMessage("%s: at most %d textures per call", who, kMaxLevels); return false; }
+	const uint32_t format = textures[0]->format;
+	const FormatEntry *f = lookup_format(format);
+	const size_t px = (size_t)detexGetPixelSize(pixel_format);
+	if (!f || !pixel_format_accepted(format, pixel_format)) {
+		for (int l = 0; l < n_textures; l++) memset(pixel_buffers[l], 0, (size_t)textures[l]->width * (size_t)textures[l]->height * px);
+		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who, format, pixel_format);
+		return false;
+	}
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	const size_t bs = detexGetCompressedBlockSize(format);
+	size_t in_off[kMaxLevels], out_off[kMaxLevels], in_total = 0, out_total = 0;
+	for (int l = 0; l < n_textures; l++) {
+		if (textures[l]->format != format) { detexSetErrorMessage("%s: all textures must share one format", who); return false; }
+		in_off[l] = in_total; out_off[l] = out_total;
+		in_total += ((size_t)textures[l]->width_in_blocks * (size_t)textures[l]->height_in_blocks * bs + 255) & ~(size_t)255;
+		out_total += ((size_t)textures[l]->width * (size_t)textures[l]->height * px + 255) & ~(size_t)255;
+	}
+	if (!reserve(&c.d_in, &c.in_cap, in_total ? in_total : 256) || !reserve(&c.d_out, &c.out_cap, out_total ? out_total : 256)) return false;
+	detexhipLevel lv[kMaxLevels];
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	for (int l = 0; l < n_textures; l++) {
+		const detexTexture *t = textures[l];
+		const size_t nbytes = (size_t)t->width_in_blocks * (size_t)t->height_in_blocks * bs;
+		if (nbytes) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(c.d_in) + in_off[l], t->data, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+		lv[l] = detexhipLevel{ static_cast<uint8_t *>(c.d_in) + in_off[l], static_cast<uint8_t *>(c.d_out) + out_off[l],
+			(size_t)t->width * px, t->width, t->height, t->width_in_blocks, t->height_in_blocks };
+	}
+	if (detexhipDecompressLevelsLinearDevice(format, lv, n_textures, pixel_format, c.stream, c.d_status) != 0) return false;
+	uint32_t status = 0;
+	for (int l = 0; l < n_textures; l++) {
+		const size_t nbytes = (size_t)textures[l]->width * (size_t)textures[l]->height * px;
+		if (nbytes) HIP_TRY(hipMemcpyAsync(pixel_buffers[l], static_cast<uint8_t *>(c.d_out) + out_off[l], nbytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	}
+	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	if (status != 0) {
+		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", format);
+		return false;
+	}
+	return true;
+}
+
+// 8f-4 host tier: histogram[m] = number of blocks whose detexGetMode<FMT> is m (bin 15: reserved codes)
+extern "C" bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks, uint32_t histogram[16]) {
+	const FormatEntry *f = lookup_format(texture_format);
+	if (!f) { detexSetErrorMessage("detexhipModeHistogram: 0x%08X is not a block-compressed format of this library", texture_format); return false; }
+	if (!context_ready()) return false;
+	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	const size_t nbytes = n_blocks * detexGetCompressedBlockSize(texture_format);
+	if (!reserve(&c.d_in, &c.in_cap, nbytes ? nbytes : 256)) return false;
+	if (nbytes) HIP_TRY(hipMemcpyAsync(c.d_in, blocks, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	uint32_t *d_hist = c.d_status;		// 16 words (the status allocation is 64 bytes)
+	if (detexhipModeHistogramDevice(texture_format, c.d_in, n_blocks, d_hist, c.stream) != 0) return false;
+	HIP_TRY(hipMemcpyAsync(histogram, d_hist, 64, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	return true;
+}
+
+extern "C" bool detexDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, true);
+}
+
+extern "C" bool detexDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, false);
+}
+
+// The same two drivers under names that do not collide with the reference's: for a libdetex that forwards its own
+// detexDecompressTextureLinear / Tiled here while both libraries are linked.
+extern "C" bool detexhipHostDecompressTextureLinear(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, false);
+}
+extern "C" bool detexhipHostDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format) {
+	return decompress_texture(texture, pixel_buffer, pixel_format, true);
+}
+

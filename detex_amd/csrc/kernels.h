@@ -21,6 +21,7 @@
 #pragma once
 #include <type_traits>
 #include "dev_common.h"
+#include "path_types.h"
 
 namespace detexhip {
 
@@ -63,21 +64,14 @@ template <> struct BlockWord<16> { using type = uint4; };
 //   FLOAT_RGBX16 (BC6H)     -> RGBX16 by lrintf(clamp01(f) * 65535 + 0.5) rounding down (half-float.c:304-312) -> RGBX8 by
 //                              the same 16 -> 8 map (:299-313): one 64 KiB lookup table per device (kHalfToU8)
 //                              FLOAT_BGRX16: swap halves 0 and 2 (:54-70)
-enum : int {
-	kEpiNone = 0,		// native pixel format (or the RGBX8 <-> RGBA8 no-op, convert.c:768-769)
-	kEpiSwapRB8 = 1,	// RGBA8/RGBX8 -> BGRA8/BGRX8
-	kEpiPackRGB8 = 2,	// RGBA8/RGBX8 -> RGB8: 4 pixels -> 3 dwords
-	kEpiSwapRB16 = 3,	// FLOAT_RGBX16 -> FLOAT_BGRX16
-	kEpiToRGBX8 = 4,	// 1/2-component and half-float natives -> RGBX8 / RGBA8 (4th byte 0xFF)
-	kEpiToBGRX8 = 5,	//                                   ... -> BGRX8 / BGRA8
-	kEpiToRGB8 = 6,		//                                   ... -> RGB8
-};
+// (the epilogue numbers kEpi... are in path_types.h: the host side of the library names them too)
 template <class Dec, class = void> struct NativeOf { static constexpr int value = kNatRGBA8; };
 template <class Dec> struct NativeOf<Dec, std::void_t<decltype(Dec::kNative)>> { static constexpr int value = Dec::kNative; };
 
 // half bit pattern -> 8-bit component of the FLOAT_RGBX16 -> RGBX16 -> RGBX8 path; filled per device by the host side
-// of the library before the first launch that needs it (detexhip.hip: ensure_half_table)
-__device__ __attribute__((aligned(16))) uint8_t kHalfToU8[65536];
+// of the library before the first launch that needs it (formats_bptc_float.hip: ensure_half_table)
+// (static: one copy per translation unit that uses it -- only the BC6H one does, and that is the copy its ensure_half_table fills)
+static __device__ __attribute__((aligned(16))) uint8_t kHalfToU8[65536];
 // The kernels look halves up in a WORKGROUP COPY of the table's live part: unsigned BC6H decodes to halves 0 .. 0x7BFF
 // (never negative, never Inf / NaN: decompress-bptc-float.c:613-621), and every half from 1.0 = 0x3C00 up converts to 255,
 // so entries 0 .. 0x3C00 with the index clamped cover all of it in 15 KiB of LDS.  48 lookups per block as per-lane

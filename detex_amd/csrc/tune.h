@@ -25,7 +25,7 @@ struct ProductTune {
 	// BC6H linear kernel: texel rows exchanged and stored as the decoder completes them (false: after the whole block -- the
 	// faster way round: DESIGN.md section 5)
 	static constexpr bool kRowWise = false;
-	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of detexhip.hip (kFormats), 0 = no cap, 3..7 = this
+	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of the formats_*.hip tables, 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
 	static constexpr int kWorkgroupsPerCu = -1;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate?
@@ -40,7 +40,7 @@ struct ProductTune {
 	// RGTC1: blocks per lane in the linear kernel
 	static constexpr int kRgtc1LaneBlocks = 4;
 	// host-pointer tier: textures whose blocks + pixels fit in this many bytes are exchanged through pinned host memory the
-	// kernel reads and writes directly (one launch + one synchronisation; detexhip.hip: direct_exchange)
+	// kernel reads and writes directly (one launch + one synchronisation; host_tier.cpp: direct_exchange)
 	static constexpr unsigned long kHostDirectBytes = 1280u << 10;	// up to 512 x 512 RGBA8 (measured: 64^2 51 -> 18 us, 256^2 83 -> 31 us per call)
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;

@@ -80,18 +80,13 @@ def test_ktx_loader_survives_a_hostile_corpus(ktx_san, tmp_path):
 
 
 def test_entry_points_refuse_hostile_arguments_under_sanitizers():
-    """tests/host_san/api_san_main.hip: the host side of detexhip.hip itself (argument validation of every entry point, the
-    error convention, the half-float table builder) built with hipcc -fsanitize=address,undefined -fno-gpu-sanitize and called
-    with arguments that must be refused.  Works without a GPU (what passes validation then fails with "no usable HIP
-    device").  The build takes about a minute and is cached next to the source."""
+    """tests/host_san/api_san_main.cpp: the host side of the library itself (argument validation of every entry point, the
+    error convention, the half-float table builder) built with hipcc -fsanitize=address,undefined -fno-gpu-sanitize (`make api-san`:
+    every translation unit of the library, instrumented, linked with the test's main) and called with arguments that must be
+    refused.  Works without a GPU (what passes validation then fails with "no usable HIP device").  The build takes about half a
+    minute and is cached (make)."""
     exe = os.path.join(SAN, "api_san")
-    csrc = os.path.join(ROOT, "detex_amd", "csrc")
-    deps = [os.path.join(SAN, "api_san_main.hip"), os.path.join(ROOT, "include", "detex.h"), os.path.join(ROOT, "include", "detexhip.h")] + \
-        [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".cpp", ".inc"))]
-    if not os.path.exists(exe) or any(os.path.getmtime(exe) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-gpu-sanitize",
-                               "-fno-sanitize-recover=all", "-Wno-unused-function", "-Wno-pass-failed", "-o", exe, deps[0], os.path.join(csrc, "ktx_loader.cpp")],
-                              stderr=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "api-san"], stderr=subprocess.DEVNULL)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")   # (the HIP runtime keeps its own allocations)
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])

@@ -55,8 +55,8 @@ for v in "$@"; do
   done
   hdr=$PWD/build/tune/tune_$name.h
   echo "struct Tune : ProductTune { $body};" > "$hdr"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $extra "-DDETEXHIP_TUNE_HEADER=\"$hdr\"" \
-    -Wall -Wno-unused-function -Wno-pass-failed -o build/explib/libdetexhip_exp_$name.so detex_amd/csrc/detexhip.hip detex_amd/csrc/ktx_loader.cpp &
+  # (one sub-make per build: its own object directory, the library's translation units compiled in parallel)
+  make -s -j4 lib LIB=build/explib/libdetexhip_exp_$name.so OBJDIR=build/obj_exp/$name EXTRA_HIPFLAGS="$extra -DDETEXHIP_TUNE_HEADER='\"$hdr\"'" &
 done
 wait
 ls -la build/explib

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Resident workgroups per CU of the linear kernels (dynamic-LDS occupancy cap, detexhip.hip: occupancy_cap_lds): every format, streams U / C
+# Resident workgroups per CU of the linear kernels (dynamic-LDS occupancy cap, launchers.h: occupancy_cap_lds): every format, streams U / C
 # (M for the BPTC formats), caps 3..7 and none (wg0).  bash tools/build_exp_libs.sh wg0 wg3 wg4 wg5 wg6 wg7 first.
 set -u
 OUT=${1:-gpurun_out/wg_sweep}; mkdir -p $OUT

@@ -3,7 +3,7 @@
    python tools/isa_mix.py 'decode_linearINS_13DecBPTCFloatTILb0ELb0EEELi0ELb1E' [--dump]   one kernel (substring of the mangled name): counts,
                                                                                              the thirty most frequent opcodes, optionally the listing
    python tools/isa_mix.py --all ['decode_linearI.*Lb1E+v']                                  one line per kernel whose name matches the regex
-Compiles detexhip.hip to assembly once (build/scratch/detexhip.s, reused while newer than the sources) and counts the instructions between
+Compiles the library's device translation units to assembly once (build/scratch/isa_*.s, reused while newer than the sources) and counts the instructions between
 a kernel's label and its s_endpgm.  The decoders are (nearly) branch-free, so the static VALU count is what a wave executes; kernels with
 wave-uniform alternatives (BC7's per-record copies, ETC2's paths) count every alternative.
 The issue-cycle estimate prices each VALU instruction with the per-class rates measured by tools/ubench/valu_rates.hip (profiles/r0*/
@@ -11,13 +11,18 @@ valu_rates.txt): adds, subs, logic ops, right shifts, moves and v_bitop3 on VGPR
 the same ops with an SGPR source 4.2, everything else (multiplies, bit-field ops, v_perm, left shifts, packed and SDWA forms) ~4.4."""
 import collections, glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-asm = os.path.join(ROOT, "build", "scratch", "detexhip.s")
 srcs = [p for ext in ("*.h", "*.hip", "*.inc") for p in glob.glob(os.path.join(ROOT, "detex_amd", "csrc", ext))]
-if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(p) for p in srcs):
-    os.makedirs(os.path.dirname(asm), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-pass-failed",
-                           "-o", asm, os.path.join(ROOT, "detex_amd", "csrc", "detexhip.hip")], stderr=subprocess.DEVNULL)
-lines = open(asm).read().splitlines()
+newest = max(os.path.getmtime(p) for p in srcs)
+lines, jobs = [], []
+for unit in sorted(glob.glob(os.path.join(ROOT, "detex_amd", "csrc", "*.hip"))):
+    asm = os.path.join(ROOT, "build", "scratch", "isa_%s.s" % os.path.splitext(os.path.basename(unit))[0])
+    if not os.path.exists(asm) or os.path.getmtime(asm) < newest:
+        os.makedirs(os.path.dirname(asm), exist_ok=True)
+        jobs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-pass-failed",
+                                      "-o", asm, unit] + os.environ.get("ISA_MIX_FLAGS", "").split(), stderr=subprocess.DEVNULL))
+    lines.append(asm)
+assert all(j.wait() == 0 for j in jobs), "hipcc failed"
+lines = [l for asm in lines for l in open(asm).read().splitlines()]
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32", "v_bitop3_b32")
 
 
