@@ -10,7 +10,7 @@ LIB   := detex_amd/lib/libdetexhip.so
 LIB_AB := build/explib/libdetexhip_ab.so
 HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/ab/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
 
-all: lib oracle ubench
+all: lib oracle ubench c-client
 lib: $(LIB)
 ubench: tools/ubench/valu_rates hbmref
 tools/ubench/valu_rates: tools/ubench/valu_rates.hip
@@ -53,10 +53,21 @@ $(OBJDIR)/api_san_main.o: tests/host_san/api_san_main.cpp include/detex.h includ
 tests/host_san/api_san: $(OBJDIR)/api_san_main.o $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -o $@ $^
 
+# a plain C client of the drop-in boundary (tests/c_client/detex_client.c; tests/test_c_client.py runs it on the GPU box): gcc, this
+# repository's detex.h, -ldetexhip with an rpath to the library; where the reference's sources are present (build container) a second
+# binary from the SAME source compiled against the REFERENCE's own detex.h -- the client a libdetex user would already have
+REFHDR ?= /root/reference
+CLIENT := tests/c_client/detex_client
+c-client: $(CLIENT) $(if $(wildcard $(REFHDR)/detex.h),$(CLIENT)_refhdr)
+$(CLIENT): $(CLIENT).c include/detex.h $(LIB)
+	gcc -std=c99 -O2 -Wall -Wextra -Iinclude -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
+$(CLIENT)_refhdr: $(CLIENT).c $(REFHDR)/detex.h $(LIB)
+	gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O2 -Wall -I$(REFHDR) -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san tools/ubench/valu_rates tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr tools/ubench/valu_rates tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib lib-ab api-san oracle ubench hbmref clean
+.PHONY: all lib lib-ab api-san c-client oracle ubench hbmref clean

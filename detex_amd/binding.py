@@ -148,7 +148,8 @@ def mode_histogram_device(fmt, blocks, n_blocks, hist=None, stream=None, accumul
 class Shard(ctypes.Structure):
     """detexhipShard (include/detexhip.h)"""
     _fields_ = [("device", ctypes.c_int), ("d_blocks", ctypes.c_void_p), ("d_pixels", ctypes.c_void_p),
-                ("row0", ctypes.c_int), ("row1", ctypes.c_int), ("decode_ms", ctypes.c_float), ("invalid_blocks", ctypes.c_int)]
+                ("row0", ctypes.c_int), ("row1", ctypes.c_int), ("decode_ms", ctypes.c_float), ("invalid_blocks", ctypes.c_int),
+                ("peer_access", ctypes.c_int)]
 
 
 def shard_rows(height_in_blocks, n_shards, shard):
@@ -224,5 +225,5 @@ def decompress_linear_multi_device(fmt, width, height, devices, host_blocks=None
         None if gathered is None else gathered.data_ptr(), ctypes.byref(t_dec), ctypes.byref(t_gat)),
         "detexhipDecompressTextureLinearMultiDevice")
     return {"ok": all(s.invalid_blocks == 0 for s in shards), "bands": bands, "gathered": gathered,
-            "shards": [(s.row0, s.row1, s.decode_ms, s.invalid_blocks) for s in shards],
+            "shards": [(s.row0, s.row1, s.decode_ms, s.invalid_blocks) for s in shards], "peer_access": [s.peer_access for s in shards],
             "decode_wall_ms": t_dec.value, "gather_wall_ms": t_gat.value}

@@ -83,16 +83,24 @@ hipError_t grow(void **buf, size_t *cap, size_t need) {		// on the current devic
 	return e;
 }
 
-// peer access device -> peer, enabled once per process and pair (the call costs milliseconds; it used to run on every gather)
+// Peer access device -> peer, established once per process and pair (the enable call costs milliseconds; it used to run on every
+// gather).  Returns true if `device` can address `peer`'s memory directly -- the copy then travels over the link between the two
+// (xGMI on an MI355X node) -- and false where the topology or the runtime does not allow it; only SUCCESS is remembered as such, a
+// pair that failed is asked about again by the next call.
 std::mutex g_peer_mutex;
 uint64_t g_peer_enabled[64];
-void enable_peer_once(int device, int peer) {			// `device` is current
-	if (device == peer || device < 0 || device >= 64 || peer < 0 || peer >= 64) return;
+bool peer_access(int device, int peer) {			// `device` is current
+	if (device == peer) return true;
+	if (device < 0 || device >= 64 || peer < 0 || peer >= 64) return false;
 	std::lock_guard<std::mutex> lock(g_peer_mutex);
-	if (g_peer_enabled[device] >> peer & 1u) return;
-	hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
-	if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();	// not fatal: the peer copy is then staged by the runtime
+	if (g_peer_enabled[device] >> peer & 1u) return true;
+	int can = 0;
+	if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+	const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+	if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+	(void)hipGetLastError();					// (hipErrorPeerAccessAlreadyEnabled is sticky otherwise)
 	g_peer_enabled[device] |= (uint64_t)1 << peer;
+	return true;
 }
 
 }  // namespace
@@ -141,7 +149,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_forma
 			if (n && (e = hipMemcpyAsync(sl.d_upload, static_cast<const uint8_t *>(host_blocks) + (size_t)sh.row0 * wb * bs, n, hipMemcpyHostToDevice,
 					sl.stream)) != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
 		}
-		if (gather_device >= 0) enable_peer_once(sh.device, gather_device);	// direct peer copies over xGMI where the topology allows
+		sh.peer_access = gather_device < 0 ? -1 : (peer_access(sh.device, gather_device) ? 1 : 0);	// direct peer copies over xGMI where the topology allows
 	}
 	for (int g = 0; g < n_shards && rc == 0; g++) {		// uploads done: the timed region starts with idle devices
 		hipError_t e = hipSetDevice(shards[g].device);
@@ -165,8 +173,12 @@ extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_forma
 			// a band is (rows - 1) * pitch + width * px bytes: one flat peer copy when rows are dense, a 2-D copy otherwise (the
 			// bytes between width * px and pitch belong to the caller, in the band and in the gathered image alike)
 			uint8_t *dst = static_cast<uint8_t *>(d_gathered) + y0 * pitch;
+			// (hipMemcpyPeerAsync names both devices, so the runtime stages the copy where there is no peer mapping; the 2-D
+			// device-to-device copy needs the mapping -- without one the rows go one hipMemcpyPeerAsync each: slow, but correct)
 			if (pitch == (size_t)width * px) e = hipMemcpyPeerAsync(dst, gather_device, sh.d_pixels, sh.device, (y1 - y0) * pitch, sl.stream);
-			else e = hipMemcpy2DAsync(dst, pitch, sh.d_pixels, pitch, (size_t)width * px, y1 - y0, hipMemcpyDeviceToDevice, sl.stream);
+			else if (sh.peer_access == 1) e = hipMemcpy2DAsync(dst, pitch, sh.d_pixels, pitch, (size_t)width * px, y1 - y0, hipMemcpyDeviceToDevice, sl.stream);
+			else for (size_t y = 0; y < y1 - y0 && e == hipSuccess; y++)
+				e = hipMemcpyPeerAsync(dst + y * pitch, gather_device, static_cast<const uint8_t *>(sh.d_pixels) + y * pitch, sh.device, (size_t)width * px, sl.stream);
 			if (e != hipSuccess) { fail("peer copy", e); break; }
 		}
 		(void)hipEventRecord(sl.e2, sl.stream);
@@ -226,6 +238,9 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 	struct Work { int rc = 0; bool invalid = false; char message[256] = { 0 }; };
 	Work work[64];
 	ShardSlots &slots = t_shards;
+	// the workers decode on behalf of the calling thread: ITS quirk mask and kernel variant apply, not the workers' own defaults
+	const uint32_t decode_flags = current_spec_flags();
+	const int variant = current_variant();
 	const auto t0 = std::chrono::steady_clock::now();
 	auto run = [&](int g) {
 		Work &w = work[g];
@@ -242,8 +257,8 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 		if ((e = grow(&sl.d_upload, &sl.upload_cap, n_in)) != hipSuccess || (e = grow(&sl.d_band, &sl.band_cap, rows * row_bytes)) != hipSuccess) { fail("hipMalloc", e); return; }
 		if ((e = hipMemsetAsync(sl.d_status, 0, 4, sl.stream)) != hipSuccess) { fail("hipMemsetAsync", e); return; }
 		if ((e = hipMemcpyAsync(sl.d_upload, static_cast<const uint8_t *>(host_blocks) + (size_t)row0 * wb * bs, n_in, hipMemcpyHostToDevice, sl.stream)) != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); return; }
-		if (detexhipDecompressTextureLinearDevice(texture_format, sl.d_upload, width, (int)rows, width_in_blocks, row1 - row0, sl.d_band, row_bytes, pixel_format,
-				sl.stream, sl.d_status) != 0) { snprintf(w.message, sizeof w.message, "%s", detexGetErrorMessage() ? detexGetErrorMessage() : "launch failed"); w.rc = 1; }
+		if (linear_device_with(texture_format, sl.d_upload, width, (int)rows, width_in_blocks, row1 - row0, sl.d_band, row_bytes, pixel_format,
+				sl.stream, sl.d_status, decode_flags, variant) != 0) { snprintf(w.message, sizeof w.message, "%s", detexGetErrorMessage() ? detexGetErrorMessage() : "launch failed"); w.rc = 1; }
 		uint8_t *dst = static_cast<uint8_t *>(host_pixels) + y0 * pitch;
 		uint32_t st = 0;
 		if (w.rc == 0) {

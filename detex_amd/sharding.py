@@ -89,9 +89,12 @@ def gather_image_to_root(dist, torch, fmt, width, height, shard, local_pixels, l
     root's xGMI links to all peers carry data at once; gloo in the CPU tests), no staging copy, bands of any (unequal)
     size.  Only 1/world of what an all-gather moves crosses each link, and nothing lands on the other ranks.
     Returns (ok, image) on the root -- ok = AND of the per-rank flags, the reference's bool result (texture.c:144) --
-    and (ok, None) elsewhere.  `image` may be a preallocated width*height*px uint8 tensor on the root."""
+    and (ok, None) elsewhere.  `image` may be a preallocated width*height*px uint8 tensor on the root.  `root` and the shard
+    ranks are ranks within `group` (the default group when None)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    # ranks below are ranks IN THE GROUP (as `root` is); P2POp addresses its peer by GLOBAL rank
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     px = fmt.pixel_bytes
     dev = local_pixels.device
     flat = local_pixels.reshape(-1)[:shard.out_bytes]
@@ -106,9 +109,9 @@ def gather_image_to_root(dist, torch, fmt, width, height, shard, local_pixels, l
             if r == root:
                 image[s.out_offset:s.out_offset + s.out_bytes] = flat
             else:
-                ops.append(dist.P2POp(dist.irecv, image[s.out_offset:s.out_offset + s.out_bytes], r, group))
+                ops.append(dist.P2POp(dist.irecv, image[s.out_offset:s.out_offset + s.out_bytes], peer(r), group))
     elif shard.out_bytes:
-        ops.append(dist.P2POp(dist.isend, flat.contiguous(), root, group))
+        ops.append(dist.P2POp(dist.isend, flat.contiguous(), peer(root), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()

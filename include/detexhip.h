@@ -75,7 +75,8 @@ DETEXHIP_API int detexhipDecompressTextureLinearDevice(uint32_t texture_format, 
  * shards[g].d_pixels (that band's rows, pitch_bytes apart; 0 = width*pixel_size).  One calling thread drives
  * all devices: per-shard streams, kernels launched back to back, HIP events for the per-device kernel time.
  * gather_device >= 0 additionally copies every band into the whole image d_gathered on that device with
- * hipMemcpyPeerAsync (direct xGMI transfers, one per source device, so all links of the root are busy);
+ * hipMemcpyPeerAsync (direct xGMI transfers, one per source device, so all links of the root are busy -- where a peer mapping
+ * exists: hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess are tried per pair and the outcome is reported in shards[g].peer_access);
  * it is timed separately and is never part of the decode time.  The call returns after everything completed:
  * 0 = ran (the reference's bool result is "no shard has invalid_blocks"), non-zero = usage / HIP error.
  * *decode_wall_ms: host clock from the first launch until the last kernel finished (uploads excluded);
@@ -83,7 +84,7 @@ DETEXHIP_API int detexhipDecompressTextureLinearDevice(uint32_t texture_format, 
  * a band is then gathered row by row and the bytes between the rows are left alone on both sides.
  * Streams, events, status words and upload buffers are per calling thread and shard index, kept between calls
  * (detexhipReleaseThreadResources() frees them): no lock is taken, concurrent callers do not share anything, and peer
- * access is enabled once per process and device pair.  On failure everything this call launched has completed
+ * access is enabled once per process and device pair (a pair that could not be enabled is tried again by the next call).  On failure everything this call launched has completed
  * before it returns.
  */
 typedef struct {
@@ -93,6 +94,9 @@ typedef struct {
 	int row0, row1;			/* out: block rows [row0, row1) */
 	float decode_ms;		/* out: kernel time on this device (HIP events) */
 	int invalid_blocks;		/* out: 1 if a block of the band was invalid (zero-filled, texture.c:125-128) */
+	int peer_access;		/* out: with a gather, 1 = `device` addresses gather_device's memory directly (the band travelled over the link
+					 * between the two: xGMI on an MI355X node; also when they are the same device), 0 = no peer mapping (topology or
+					 * runtime refused it): the runtime staged the copy -- gather_wall_ms is then NOT an xGMI figure; -1 = no gather */
 } detexhipShard;
 DETEXHIP_API int detexhipShardRows(int height_in_blocks, int n_shards, int shard, int *row0, int *row1);
 DETEXHIP_API int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_format, const void *host_blocks,

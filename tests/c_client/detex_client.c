@@ -1,0 +1,131 @@
+/* tests/c_client/detex_client.c -- TEST-ONLY: a plain C program that uses libdetexhip the way the reference's own programs use
+ * libdetex (validate.c:135,199-209: detexLoadKTXFile -> detexDecompressTextureLinear; detex.h:747-765, 826-836).  No Python, no
+ * torch: compiled with gcc against a detex.h (this repository's, or the REFERENCE's own header where it is available at build
+ * time -- the binary is the same client either way) and linked with -ldetexhip instead of -ldetex.  It prints one line per
+ * input with the sha256 of the decoded pixels, which tests/test_c_client.py compares with the compiled reference's digests.
+ *
+ *   detex_client file.ktx ...            each file: load, decode into the format's native pixel format, digest
+ *   detex_client --stream FORMAT BLOCKBYTES SEED W H     synthetic block stream U (splitmix64) of texture format word
+ *                                                        FORMAT (detex.h:613-727), decoded and digested the same way
+ *   detex_client --sha256-selftest       digest of "abc" and of 1,000,000 'a' (FIPS 180-4 vectors)
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "detex.h"
+
+/* ---- sha256 (FIPS 180-4), written for this test ------------------------------------------------------------------------------ */
+static const uint32_t K256[64] = {
+	0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+	0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+	0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+	0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+	0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+	0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2 };
+typedef struct { uint32_t h[8]; uint64_t bytes; uint8_t buf[64]; size_t fill; } Sha256;
+static uint32_t ror(uint32_t v, int s) { return (v >> s) | (v << (32 - s)); }
+static void sha_block(Sha256 *c, const uint8_t *p) {
+	uint32_t w[64], a[8];
+	for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+	for (int i = 16; i < 64; i++) {
+		const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+		w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+	}
+	memcpy(a, c->h, sizeof a);
+	for (int i = 0; i < 64; i++) {
+		const uint32_t t1 = a[7] + (ror(a[4], 6) ^ ror(a[4], 11) ^ ror(a[4], 25)) + ((a[4] & a[5]) ^ (~a[4] & a[6])) + K256[i] + w[i];
+		const uint32_t t2 = (ror(a[0], 2) ^ ror(a[0], 13) ^ ror(a[0], 22)) + ((a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]));
+		a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+	}
+	for (int i = 0; i < 8; i++) c->h[i] += a[i];
+}
+static void sha_init(Sha256 *c) {
+	static const uint32_t h0[8] = { 0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 };
+	memcpy(c->h, h0, sizeof h0); c->bytes = 0; c->fill = 0;
+}
+static void sha_update(Sha256 *c, const uint8_t *p, size_t n) {
+	c->bytes += n;
+	if (c->fill) {
+		const size_t take = 64 - c->fill < n ? 64 - c->fill : n;
+		memcpy(c->buf + c->fill, p, take); c->fill += take; p += take; n -= take;
+		if (c->fill == 64) { sha_block(c, c->buf); c->fill = 0; }
+	}
+	for (; n >= 64; p += 64, n -= 64) sha_block(c, p);
+	if (n) { memcpy(c->buf, p, n); c->fill = n; }
+}
+static void sha_hex(Sha256 *c, char out[65]) {
+	const uint64_t bits = c->bytes * 8;
+	uint8_t pad[72] = { 0x80 };
+	const size_t padlen = (c->fill < 56 ? 56 : 120) - c->fill;
+	for (int i = 0; i < 8; i++) pad[padlen + i] = (uint8_t)(bits >> (56 - 8 * i));
+	sha_update(c, pad, padlen + 8);
+	for (int i = 0; i < 8; i++) sprintf(out + 8 * i, "%08x", c->h[i]);
+}
+static void sha256_of(const uint8_t *p, size_t n, char out[65]) { Sha256 c; sha_init(&c); sha_update(&c, p, n); sha_hex(&c, out); }
+
+/* ---- the client --------------------------------------------------------------------------------------------------------------- */
+static int decode_and_print(const char *label, const detexTexture *t) {
+	const uint32_t pixel_format = detexGetPixelFormat(t->format);
+	const size_t bytes = (size_t)t->width * (size_t)t->height * (size_t)detexGetPixelSize(pixel_format);
+	uint8_t *pixels = (uint8_t *)malloc(bytes ? bytes : 1);
+	if (!pixels) { printf("%s ERROR out of memory\n", label); return 1; }
+	memset(pixels, 0xEE, bytes);
+	const bool ok = detexDecompressTextureLinear(t, pixels, pixel_format);	/* the reference's call: texture.c:105, validate.c:208 */
+	const char *message = detexGetErrorMessage();
+	if (!ok && (!message || !strstr(message, "returned error"))) {		/* not "a block was invalid" but a failure of the library */
+		printf("%s ERROR %s\n", label, message ? message : "(no message)");
+		free(pixels);
+		return 1;
+	}
+	char hex[65];
+	sha256_of(pixels, bytes, hex);
+	printf("%s format=0x%08X %dx%d ok=%d sha256=%s\n", label, t->format, t->width, t->height, ok ? 1 : 0, hex);
+	free(pixels);
+	return 0;
+}
+
+int main(int argc, char **argv) {
+	if (argc >= 2 && !strcmp(argv[1], "--sha256-selftest")) {
+		char hex[65];
+		sha256_of((const uint8_t *)"abc", 3, hex); printf("abc %s\n", hex);
+		uint8_t *a = (uint8_t *)malloc(1000000); memset(a, 'a', 1000000);
+		sha256_of(a, 1000000, hex); printf("million_a %s\n", hex);
+		free(a);
+		return 0;
+	}
+	if (argc == 7 && !strcmp(argv[1], "--stream")) {
+		const uint32_t format = (uint32_t)strtoul(argv[2], NULL, 0), block_bytes = (uint32_t)strtoul(argv[3], NULL, 0);
+		uint64_t state = strtoull(argv[4], NULL, 0);
+		const int w = atoi(argv[5]), h = atoi(argv[6]);
+		const size_t n_words = (size_t)(w / 4) * (size_t)(h / 4) * block_bytes / 8;
+		uint64_t *words = (uint64_t *)malloc(n_words ? n_words * 8 : 8);
+		if (!words) { printf("stream ERROR out of memory\n"); return 1; }
+		for (size_t k = 0; k < n_words; k++) {			/* splitmix64 */
+			state += 0x9E3779B97F4A7C15ull;
+			uint64_t z = state;
+			z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+			z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+			words[k] = z ^ (z >> 31);
+		}
+		detexTexture t;
+		t.format = format; t.data = (uint8_t *)words; t.width = w; t.height = h; t.width_in_blocks = w / 4; t.height_in_blocks = h / 4;
+		const int rc = decode_and_print("stream", &t);
+		free(words);
+		return rc;
+	}
+	int failures = 0;
+	for (int i = 1; i < argc; i++) {
+		detexTexture *texture = NULL;
+		if (!detexLoadKTXFile(argv[i], &texture)) {		/* ktx.c:180, validate.c:135 */
+			printf("%s ERROR %s\n", argv[i], detexGetErrorMessage() ? detexGetErrorMessage() : "(no message)");
+			failures++;
+			continue;
+		}
+		failures += decode_and_print(argv[i], texture);
+		free(texture->data);					/* the caller owns both (ktx.c:150-176) */
+		free(texture);
+	}
+	return failures ? 1 : 0;
+}

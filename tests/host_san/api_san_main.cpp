@@ -83,7 +83,7 @@ int main() {
 	REFUSED(detexhipShardRows(-1, 4, 0, &r0, &r1) == 0);
 	REFUSED(detexhipShardRows(8, 4, 0, nullptr, &r1) == 0);
 	if (detexhipShardRows(0x7FFFFFFF, 64, 63, &r0, &r1) != 0 || r1 != 0x7FFFFFFF || r0 < 0 || r0 > r1) { printf("detexhipShardRows overflows\n"); g_failures++; }
-	detexhipShard sh[2] = { { 0, nullptr, out, 0, 0, 0.f, 0 }, { 0, nullptr, out, 0, 0, 0.f, 0 } };
+	detexhipShard sh[2] = { { 0, nullptr, out, 0, 0, 0.f, 0, 0 }, { 0, nullptr, out, 0, 0, 0.f, 0, 0 } };
 	float ms = 0;
 	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, nullptr, 2, -1, nullptr, &ms, &ms) == 0);
 	REFUSED(detexhipDecompressTextureLinearMultiDevice(BC1, in, 8, 8, 2, 2, 0, RGBA8, sh, 0, -1, nullptr, &ms, &ms) == 0);

@@ -138,6 +138,11 @@ def test_multi_device_entry_matches_single_device(name, W, H, shards, torch_cuda
     assert [s[0] for s in r["shards"]][0] == 0 and r["shards"][-1][1] == hb
     assert all(a[1] == b[0] for a, b in zip(r["shards"], r["shards"][1:]))
     assert r["decode_wall_ms"] > 0 and all(s[2] >= 0 for s in r["shards"])
+    # peer mapping towards the gather device, per shard: same device -> 1; another device -> whatever the topology gives, reported not hidden
+    assert all(p == 1 for p, d in zip(r["peer_access"], devices) if d == 0) and all(p in (0, 1) for p in r["peer_access"])
+    if ndev > 1:        # gathered on the LAST device instead: every other shard crosses a link
+        r3 = binding.decompress_linear_multi_device(fmt, W, H, devices, host_blocks=data, gather_device=ndev - 1)
+        assert np.array_equal(r3["gathered"].cpu().numpy(), want) and all(p in (0, 1) for p in r3["peer_access"])
     # blocks already resident on the devices
     dblocks = []
     for g, dev in enumerate(devices):
@@ -146,7 +151,7 @@ def test_multi_device_entry_matches_single_device(name, W, H, shards, torch_cuda
         dblocks.append(torch.from_numpy(np.ascontiguousarray(chunk) if chunk.size else np.zeros(16, np.uint8)).to("cuda:%d" % dev))
     r2 = binding.decompress_linear_multi_device(fmt, W, H, devices, device_blocks=dblocks)
     got2 = np.concatenate([b.cpu().numpy()[:max(0, min(s[1] * 4, H) - s[0] * 4) * W * fmt.pixel_bytes] for b, s in zip(r2["bands"], r2["shards"])])
-    assert np.array_equal(got2, want) and r2["gathered"] is None
+    assert np.array_equal(got2, want) and r2["gathered"] is None and all(p == -1 for p in r2["peer_access"])
     # a sample of the result against the CPU oracle, so the comparison above is not GPU against GPU only
     rows = min(hb, 8)
     _, ref_rows = oracle.linear(fmt, data[:rows * wb * fmt.block_bytes], W, min(rows * 4, H))

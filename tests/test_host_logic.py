@@ -213,6 +213,22 @@ def _gloo_worker(rank, world, port, q):
             ok_root, image_root = sharding.gather_image_to_root(dist, torch, fmt, w, h, shard, local, ok, root=root)
             results.append((name + " to root", ok_root == ok_ref,
                             bool(np.array_equal(image_root.numpy(), want)) if rank == root else image_root is None))
+        if world >= 4:
+            # a sub-group whose group ranks differ from the global ones (global 1 and 3 are its ranks 0 and 1): the image is sharded over
+            # the GROUP and gathered to the group's rank 1 (= global 3); point-to-point peers must be translated to global ranks
+            members = [1, 3]
+            sub = dist.new_group(members, backend="gloo")          # (every rank of the default group takes part in the creation)
+            if rank in members:
+                fmt, (w, h) = F.BY_NAME["BC3"], (64, 40)
+                data = ol.stream_u(fmt, 16 * 10, seed=99)
+                grank = members.index(rank)
+                shard, ok, local = sharding.decode_shard(lambda f, band, width, rows: (lambda r: (r[0], torch.from_numpy(r[1])))(orc.linear(f, np.ascontiguousarray(band), width, rows)),
+                                                         fmt, data, w, h, grank, len(members))
+                ok_root, image_root = sharding.gather_image_to_root(dist, torch, fmt, w, h, shard, local, ok, root=1, group=sub)
+                ok_ref, want = orc.linear(fmt, data, w, h)
+                results.append(("sub-group to root", ok_root == ok_ref, bool(np.array_equal(image_root.numpy(), want)) if grank == 1 else image_root is None))
+                ok_all, image = sharding.gather_image(dist, torch, fmt, w, h, shard, local, ok, group=sub)
+                results.append(("sub-group to all", ok_all == ok_ref, bool(np.array_equal(image.numpy(), want))))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, results))

@@ -156,6 +156,14 @@ def test_library_switch_matches_checker(quirks, gpu_lib, oracle, hiplib):
             assert np.array_equal(got_c.cpu().numpy(), want_c)
             ok_h, got_h = hiplib.linear(fmt, data, W, H)                                # host tier, and the one-block leaf function
             assert np.array_equal(got_h, want_l)
+            # the multi-device entries: the host-image one decodes in worker threads, which must apply the CALLER's mask (one shard runs
+            # inline, two and three in workers); the device one in the calling thread
+            ndev = gpu_lib.detexhipGetDeviceCount()
+            for shards in (1, 2, 3):
+                _, got_m, _ = binding.decompress_linear_multi_device_host(fmt, data, W, H, [g % ndev for g in range(shards)])
+                assert np.array_equal(got_m, want_l), (fmt.name, quirks, shards)
+            r = binding.decompress_linear_multi_device(fmt, W, H, [g % ndev for g in range(2)], host_blocks=data, gather_device=0)
+            assert np.array_equal(r["gathered"].cpu().numpy(), want_l)
             for i in (0, 5, 1023, 1500):
                 ok_b, px = hiplib.block(fmt, blocks[i])
                 assert ok_b == ok_o[i] and (not ok_b or np.array_equal(px, want[i]))
