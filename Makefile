@@ -12,7 +12,9 @@ HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/ab/*.h) $(CSRC)/bptc_tables.
 
 all: lib oracle ubench c-client
 lib: $(LIB)
-ubench: tools/ubench/valu_rates hbmref
+ubench: tools/ubench/valu_rates tools/ubench/host_latency hbmref
+tools/ubench/host_latency: tools/ubench/host_latency.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -o $@ $<
 tools/ubench/valu_rates: tools/ubench/valu_rates.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 # HBM fill / copy reference kernels bench.py times beside the decode kernel (measurement tooling, not product)

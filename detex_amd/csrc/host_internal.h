@@ -48,9 +48,9 @@ struct BatchArgs {
 	hipStream_t stream; bool checked; int epi; int resident;
 };
 // one block handed over as a kernel argument (kernels_extra.h: decode_single)
-struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; };
+struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; uint32_t *done; uint32_t ticket; };
 // 8f-3: all levels of a mip chain in one launch (kernels_extra.h: decode_levels)
-struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; uint32_t decode_flags; };
+struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; uint32_t decode_flags; Completion completion; };
 
 // One row per block format (texture.c:27-48 is the reference's table of decompress functions): the launchers of its kernels.
 struct FormatEntry {

@@ -22,7 +22,8 @@ struct ThreadContext {
 	hipStream_t stream = nullptr;
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
-	uint32_t *d_status = nullptr;	// [0] status word, [1..] ok bytes of the one-block calls / histogram bins
+	uint32_t *d_status = nullptr;	// [0] status word, [0..15] histogram bins, [16] the workgroup counter of the small calls' completion (Completion::counter)
+	uint32_t ticket = 0;		// last completion ticket handed out (never 0: the completion word starts as 0)
 	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
 	uint8_t *h_pin = nullptr, *d_pin = nullptr;
 	size_t pin_cap = 0;
@@ -79,7 +80,8 @@ bool context_ready() {
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
 	HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
-	HIP_TRY(hipMalloc(&c.d_status, 64), "hipMalloc(status)");
+	HIP_TRY(hipMalloc(&c.d_status, 128), "hipMalloc(status)");
+	HIP_TRY(hipMemset(c.d_status, 0, 128), "hipMemset(status)");
 	c.ready = true;
 	return true;
 }
@@ -98,7 +100,9 @@ bool reserve(void **buf, size_t *cap, size_t need) {
 // blocks are placed in a pinned, device-visible host buffer and the kernel reads them from there and writes pixels, ok bytes
 // and the status word back into it -- ONE launch and one stream synchronisation instead of memset + upload + launch + two
 // downloads (five runtime calls that cost more than the kernel's PCIe traffic for a few KiB).  Layout of the buffer:
-// [status word, ok byte: 256 B][blocks, 256-byte aligned][pixels, 256-byte aligned].
+// [status word, ok byte, completion word: 256 B][blocks, 256-byte aligned][pixels, 256-byte aligned].
+// The caller does not wait for the stream either: the kernel releases a completion word in the same buffer after its last store
+// and the caller polls it (wait_for_ticket; path_types.h: Completion has the measurements).
 struct DirectExchange { uint8_t *h_base, *d_base; size_t in_off, out_off; };
 bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, DirectExchange *x) {
 	const size_t in_off = 256, out_off = in_off + ((in_bytes + 255) & ~(size_t)255), need = out_off + ((out_bytes + 255) & ~(size_t)255);
@@ -113,6 +117,24 @@ bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, Direct
 	}
 	*x = DirectExchange{ c.h_pin, c.d_pin, in_off, out_off };
 	return true;
+}
+constexpr size_t kDoneOffset = 8;		// the completion word inside the exchange buffer's header
+uint32_t next_ticket(ThreadContext &c) { if (++c.ticket == 0u) c.ticket = 1u; return c.ticket; }
+// Spins on the completion word the kernel just launched on c.stream releases.  Every 2^14 polls (a few hundred microseconds) the
+// stream is asked whether it failed or finished without the word (a kernel that faulted never publishes): no unbounded wait.
+bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket) {
+	const uint32_t *word = reinterpret_cast<const uint32_t *>(x.h_base + kDoneOffset);
+	for (uint32_t polls = 1;; polls++) {
+		if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == ticket) return true;
+		__builtin_ia32_pause();
+		if ((polls & 0x3FFFu) == 0u) {
+			const hipError_t e = hipStreamQuery(c.stream);
+			if (e == hipErrorNotReady) continue;
+			if (e == hipSuccess && __atomic_load_n(word, __ATOMIC_ACQUIRE) == ticket) return true;
+			detexSetErrorMessage("libdetexhip: the kernel did not complete: %s", e == hipSuccess ? "completion word not written" : hipGetErrorString(e));
+			return false;
+		}
+	}
 }
 
 // shared by the 19 leaf functions and detexDecompressBlock: one block through the GPU.
@@ -131,10 +153,11 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	auto run = [&]() -> bool {
 		const int epi = prepared_epilogue(f->texture_format, pixel_format);
 		if (epi == -2) return false;
-		SingleArgs a{ bitstring, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi };
+		const uint32_t ticket = next_ticket(c);
+		SingleArgs a{ bitstring, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi,
+			reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), ticket };
 		HIP_TRY(f->single(a), "kernel launch");
-		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-		return true;
+		return wait_for_ticket(c, x, ticket);
 	};
 	if (!run()) return -1;
 	if (!x.h_base[4]) return 0;
@@ -251,14 +274,25 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
 		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
 		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
-		int rc;
-		if (tiled)
-			rc = detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st);
-		else
-			rc = detexhipDecompressTextureLinearDevice(texture->format, x.d_base + x.in_off, (int)width, (int)height, (int)wb, (int)hb, x.d_base + x.out_off,
-				width * px, pixel_format, c.stream, d_st);
-		if (rc != 0) return false;
-		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		if (tiled) {
+			if (detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st) != 0) return false;
+			HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		} else {
+			// the one-level form of the mip-chain kernel (any geometry in one launch), which publishes the completion word
+			const int epi = prepared_epilogue(texture->format, pixel_format);
+			if (epi == -2) return false;
+			const uint32_t ticket = next_ticket(c);
+			LevelsArgs a{};
+			a.status = d_st; a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
+			a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket };
+			a.table.n_levels = 1;
+			LevelDesc &lv = a.table.level[0];
+			lv.blocks = x.d_base + x.in_off; lv.pixels = x.d_base + x.out_off; lv.pitch = width * px;
+			lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * hb); lv.width = (uint32_t)width; lv.height = (uint32_t)height;
+			a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
+			HIP_TRY(f->levels(a), "kernel launch");
+			if (!wait_for_ticket(c, x, ticket)) return false;
+		}
 		const uint8_t *res = x.h_base + x.out_off;
 		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
 		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);

@@ -16,9 +16,11 @@ namespace detexhip {
 // call is one launch and one synchronisation, with no read across PCIe at all (the batched kernel fetching its single block
 // from host memory measured 19.8 us per call, upload + launch + two downloads 16.7).  Every lane decodes the same block (the
 // table copy and the per-lane LDS rows of the BPTC decoders want the whole workgroup); lane 0 stores.
+// Completion: the host does not wait for the stream but polls *done, a word in the same pinned buffer, which lane 0 releases at
+// system scope after its stores (path_types.h: Completion).
 template <class Dec, int EPI>
 __global__ __launch_bounds__(256) void decode_single(const typename BlockWord<Dec::kBlockBytes>::type blk, uint32_t mode_mask, uint32_t flags,
-		uint32_t *__restrict__ pixels, uint8_t *__restrict__ ok_out) {
+		uint32_t *__restrict__ pixels, uint8_t *__restrict__ ok_out, uint32_t *__restrict__ done, uint32_t ticket) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
@@ -28,19 +30,27 @@ __global__ __launch_bounds__(256) void decode_single(const typename BlockWord<De
 #pragma unroll
 		for (int k = 0; k < 4 * ROW; k++) pixels[k] = o[k];
 		*ok_out = ok ? 1 : 0;
+		if (done) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);	// (release: the stores above are visible to the host first)
 	}
 }
 
-template <class Dec, int EPI>
-__global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status, uint32_t decode_flags) {
+// the workgroup's part of a grid-wide completion (every thread of the workgroup calls this after its last store; path_types.h)
+DH void publish_completion(const Completion &c) {
+	if (c.done == nullptr) return;				// kernel argument: uniform
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");		// system scope: this thread's stores (pixels, status word) are on their way to host memory
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t finished = __hip_atomic_fetch_add(c.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+		if (finished == gridDim.x) {
+			__hip_atomic_store(c.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(c.done, c.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
+// one workgroup's 256 blocks of one level
+template <class Dec, int EPI> DH void decode_level_tile(const LevelDesc &lv, uint32_t i, uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
-	prepare_tables<Dec>();
-	prepare_epilogue<Dec, EPI>();
-	// workgroup -> level: wave-uniform scalar search over <= 16 entries
-	uint32_t l = 0;
-	for (uint32_t k = 1; k < table.n_levels; k++) l = blockIdx.x >= table.wg_start[k] ? k : l;
-	const LevelDesc &lv = table.level[l];
-	const uint32_t i = (blockIdx.x - table.wg_start[l]) * 256u + threadIdx.x;
 	if constexpr (ROW == 8) {
 		if (lv.fast) {		// workgroup-uniform (a workgroup never spans two levels): 64-bit pixels leave through the LDS transpose
 			const bool live = i < lv.n_blocks;
@@ -71,6 +81,19 @@ __global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uin
 		}
 	}
 	raise_status(!ok, status);
+}
+
+// Also the kernel of the host tier's small textures (one level, blocks and pixels in pinned host memory): `completion` then names the
+// word the last workgroup releases for the polling caller (path_types.h: Completion; {nullptr, ...} otherwise).
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256) void decode_levels(const LevelTable table, uint32_t *__restrict__ status, uint32_t decode_flags, const Completion completion) {
+	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
+	// workgroup -> level: wave-uniform scalar search over <= 16 entries
+	uint32_t l = 0;
+	for (uint32_t k = 1; k < table.n_levels; k++) l = blockIdx.x >= table.wg_start[k] ? k : l;
+	decode_level_tile<Dec, EPI>(table.level[l], (blockIdx.x - table.wg_start[l]) * 256u + threadIdx.x, status, decode_flags);
+	publish_completion(completion);
 }
 
 }  // namespace detexhip

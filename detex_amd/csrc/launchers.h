@@ -173,7 +173,7 @@ template <class Dec> hipError_t launch_single(const SingleArgs &a) {
 	typename BlockWord<Dec::kBlockBytes>::type blk;
 	memcpy(&blk, a.bitstring, sizeof blk);
 	return with_epilogue<Dec>(a.epi, [&](auto epi) {
-		hipLaunchKernelGGL((decode_single<Plain, decltype(epi)::value>), dim3(1), dim3(256), 0, a.stream, blk, a.mode_mask, a.flags, a.pixels, a.ok);
+		hipLaunchKernelGGL((decode_single<Plain, decltype(epi)::value>), dim3(1), dim3(256), 0, a.stream, blk, a.mode_mask, a.flags, a.pixels, a.ok, a.done, a.ticket);
 		return hipGetLastError();
 	});
 }
@@ -189,7 +189,7 @@ template <class Dec, int EPI> hipError_t launch_levels_epi(LevelsArgs &a) {
 	}
 	const uint32_t grid = a.table.wg_start[a.table.n_levels];
 	if (grid == 0) return hipSuccess;
-	hipLaunchKernelGGL((decode_levels<typename PlainDecoder<Dec>::type, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status, a.decode_flags);
+	hipLaunchKernelGGL((decode_levels<typename PlainDecoder<Dec>::type, EPI>), dim3(grid), dim3(256), 0, a.stream, a.table, a.status, a.decode_flags, a.completion);
 	return hipGetLastError();
 }
 template <class Dec> hipError_t launch_levels(LevelsArgs &a) {

@@ -38,6 +38,15 @@ struct LevelTable {
 	LevelDesc level[kMaxLevels];
 };
 
+// ---- completion word of the host tier's small calls (host_tier.cpp: wait_for_ticket) ---------------------------------------------------
+// A host-pointer caller of a small decode waits for ONE kernel.  Waiting through the runtime (hipStreamSynchronize: the command
+// processor's end-of-kernel release, a signal, the runtime's wait) measured 12.5 / 14.3 us per call for a one-block / a 64x64 kernel
+// on the test box; a word in pinned host memory that the kernel itself releases after its last store, polled by the caller, 9.0 /
+// 10.9 (tools/ubench/host_latency.hip; profiles/r04/host_latency.txt).  `done` = device view of that word (nullptr: no completion
+// signalling), `ticket` = the value to publish, `counter` = a zeroed device word the workgroups of a grid count themselves on (the
+// last one to finish publishes, and zeroes it again for the next launch).
+struct Completion { uint32_t *done; uint32_t *counter; uint32_t ticket; };
+
 // ---- 8f-4: how a format's blocks are classified into modes (histogram.hip: block_mode) -------------------------------------------------
 enum : int { kClassS3TC = 0, kClassS3TCat8, kClassETC1, kClassETC2, kClassETC2PT, kClassETC2at8, kClassBPTC, kClassBPTCFloat, kClassNone };
 

@@ -8,11 +8,16 @@
  *   detex_client --stream FORMAT BLOCKBYTES SEED W H     synthetic block stream U (splitmix64) of texture format word
  *                                                        FORMAT (detex.h:613-727), decoded and digested the same way
  *   detex_client --sha256-selftest       digest of "abc" and of 1,000,000 'a' (FIPS 180-4 vectors)
+ *   detex_client --latency               microseconds per call (median of 2000) of detexDecompressBlockBC1 and of
+ *                                        detexDecompressTextureLinear on 64x64 / 256x256 BC1 textures: what a C caller pays, without
+ *                                        the ctypes overhead bench.py's host_tier_small carries
  */
+#define _POSIX_C_SOURCE 200809L
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "detex.h"
 
@@ -86,7 +91,40 @@ static int decode_and_print(const char *label, const detexTexture *t) {
 	return 0;
 }
 
+static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
+static int cmp_double(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
+
+static int latency(void) {
+	enum { N = 2000, WARM = 200 };
+	static double t[N];
+	uint8_t block[8] = { 0x12, 0x34, 0x56, 0x78, 0x9A, 0xBC, 0xDE, 0xF0 }, px[64];
+	for (int i = -WARM; i < N; i++) {
+		const double t0 = now_us();
+		if (!detexDecompressBlockBC1(block, DETEX_MODE_MASK_ALL, 0, px)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
+		if (i >= 0) t[i] = now_us() - t0;
+	}
+	qsort(t, N, sizeof t[0], cmp_double);
+	printf("latency one_block_us=%.2f p90=%.2f\n", t[N / 2], t[N * 9 / 10]);
+	for (int side = 64; side <= 256; side *= 4) {
+		const size_t nb = (size_t)(side / 4) * (side / 4);
+		uint8_t *blocks = (uint8_t *)malloc(nb * 8), *pixels = (uint8_t *)malloc((size_t)side * side * 4);
+		for (size_t k = 0; k < nb * 8; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
+		detexTexture tex;
+		tex.format = DETEX_TEXTURE_FORMAT_BC1; tex.data = blocks; tex.width = side; tex.height = side; tex.width_in_blocks = side / 4; tex.height_in_blocks = side / 4;
+		for (int i = -WARM; i < N; i++) {
+			const double t0 = now_us();
+			if (!detexDecompressTextureLinear(&tex, pixels, DETEX_PIXEL_FORMAT_RGBA8)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
+			if (i >= 0) t[i] = now_us() - t0;
+		}
+		qsort(t, N, sizeof t[0], cmp_double);
+		printf("latency %dx%d_us=%.2f p90=%.2f\n", side, side, t[N / 2], t[N * 9 / 10]);
+		free(blocks); free(pixels);
+	}
+	return 0;
+}
+
 int main(int argc, char **argv) {
+	if (argc >= 2 && !strcmp(argv[1], "--latency")) return latency();
 	if (argc >= 2 && !strcmp(argv[1], "--sha256-selftest")) {
 		char hex[65];
 		sha256_of((const uint8_t *)"abc", 3, hex); printf("abc %s\n", hex);
