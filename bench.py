@@ -14,7 +14,8 @@ prints ONE JSON line on rank 0.
             (splitmix64, tests/oracle_lib.py).  Extra keys: `per_format` (the six headline formats
             of configs[1..4] at 8192^2, streams U/M/C, plus the weakest kernels -- signed BC6H,
             block-major BC7, RGTC1 -- each timed at steady state), `beyond_mall`,
-            `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`,
+            `per_format.beyond_cache_16384` (the six headline formats at 16384^2), `cold` (first launch after idle, mean of the first
+            twenty, the contract's W + K started cold), `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`,
             `host_tier_small` (per-call latency of small textures / one block through the host API,
             beside the reference on one host thread), `cpu_baseline`.
   N > 1     BASELINE north_star: ONE 32768 x 32768 BC1 image sharded by block rows over the ranks
@@ -25,11 +26,14 @@ prints ONE JSON line on rank 0.
             separately and never part of `value`: `to_root` = grouped point-to-point sends into one
             rank's image, `to_all` = one all_gather_into_tensor), `bc6h_32768` (BASELINE configs[4]:
             BPTC_FLOAT -> FLOAT_RGBX16, 32768^2 over the ranks, decode-only + its gathers, rank 0's
-            whole band checked against the reference's digest when N = 8), `rccl_ranks` (ranks that
-            answered an all_reduce).  --weak restores the round-1 line.
+            EVERY rank's whole band checked against the reference's digests, as is every rank's band of the headline image:
+            `whole_band_digests_match_reference_all_ranks`), `rccl_ranks` (ranks that answered an all_reduce; the run exits with
+            code 5 unless that is N, one rank per distinct GPU).  --weak restores the round-1 line.
   roofline  algorithmic bytes per launch (blocks * (block_bytes + 16*pixel_bytes)) / average
             launch duration from HIP events recorded on the launch stream around the timed
-            region; peak = 8 TB/s (MI355X_MICROARCH.md).  Measured in the same process beside it
+            region; peak = 8 TB/s (MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from
+            rocprofv3 PMC counters collected DURING this run (live_pmc_traffic; `traffic_source` says "REPLAYED" when it had to fall
+            back to profiles/pmc_traffic.json).  Measured in the same process beside it
             (tools/ubench/hbm_ref.hip): ref_fill_GBps = a write-only fill of 1 GiB with the decode
             kernels' store shape, ref_fill_same_shape_GBps = that fill over the workload's own
             output image, ref_copy_GBps = a 1 GiB 16-byte-vector copy (read + written);
@@ -116,6 +120,97 @@ def cpu_baseline(fmt, data, width, height, budget_s=12.0):
             "value_1thread": round(gp / t1, 4)}
 
 
+class Telemetry:
+    """shader clock and package power of the GPU this process decodes on, read from the amdgpu driver's hwmon files (freq1_input in Hz,
+    power1_input in microwatts: two small reads, ~20 us) by a sampling thread while a kernel loop runs; None where the files are absent."""
+
+    def __init__(self, torch, device_index):
+        self.dir = None
+        try:
+            import glob
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            cand = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            if not cand:                                     # (no PCI ids from torch: the one card rocm-smi would show)
+                cand = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))[:1]
+            for d in cand:
+                if os.path.exists(os.path.join(d, "freq1_input")):
+                    self.dir = d
+                    break
+        except Exception as e:  # noqa
+            log("telemetry unavailable:", e)
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except Exception:  # noqa
+            return None
+
+    def during(self, fn, seconds=0.15):
+        """run fn() repeatedly for `seconds` while sampling; returns {"sclk_mhz", "power_w", "samples"} of the second half of the samples"""
+        if self.dir is None:
+            return None
+        import threading
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                samples.append((self._read("freq1_input"), self._read("power1_input")))
+                time.sleep(0.002)
+        t = threading.Thread(target=poll)
+        t.start()
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            fn()
+        stop.set()
+        t.join()
+        tail = [x for x in samples[len(samples) // 2:] if x[0] is not None]
+        if not tail:
+            return None
+        row = {"sclk_mhz": round(sum(x[0] for x in tail) / len(tail) / 1e6), "samples": len(tail)}
+        pw = [x[1] for x in tail if x[1] is not None]
+        if pw:
+            row["power_w"] = round(sum(pw) / len(pw) / 1e6)
+        return row
+
+
+def live_pmc_traffic(fmt_name, side, layout="linear", timeout_s=150):
+    """HBM bytes per launch of the decode kernel from rocprofv3 PMC counters, collected NOW on this box: two separate passes (FETCH_SIZE,
+    WRITE_SIZE; --pmc with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) over a child process that launches the same
+    kernel a few times (tools/gpu_run_case.py); FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of a wide streaming read at 64 B).
+    Returns a dict or None (tool absent, bench.py itself under a profiler, or a pass failed)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):     # bench.py is being profiled itself: no nested profiler
+        return None
+    kernel = "decode_linear" if layout == "linear" else "decode_blocks"
+    out, tmp = {}, tempfile.mkdtemp(prefix="detex_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "gpu_run_case.py"), fmt_name, "U", str(side), str(side), "0", "6", layout]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            rows = [row for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) for row in csv.DictReader(open(f))
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            v = sorted(float(row["Counter_Value"]) for row in rows)
+            if r.returncode != 0 or not v:
+                return None
+            out[ctr] = v[len(v) // 2]
+            out["launches_" + ctr] = len(v)
+        fetch, write = out["FETCH_SIZE"] * 1024 * 2, out["WRITE_SIZE"] * 1024
+        return {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write), "profiled_launches": out["launches_WRITE_SIZE"],
+                "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes with --kernel-trace only) over tools/gpu_run_case.py, "
+                          "median of the profiled %s launches; FETCH_SIZE KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB" % kernel}
+    except Exception as e:  # noqa
+        log("live PMC pass failed:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +265,18 @@ def main():
         ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())          # ranks the collective library actually reached
+        # one rank per GPU, every rank reached: anything else is not the N-GPU measurement the line would claim -- fail loudly
+        prop = torch.cuda.get_device_properties(device_index)
+        mine = torch.tensor([device_index, getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1), getattr(prop, "pci_domain_id", -1)],
+                            dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        places = [tuple(int(v) for v in t.tolist()) for t in seen]
+        if backend == "nccl" and (rccl_ranks != world or args.gpus != world or len(set(places)) != world or world > torch.cuda.device_count()):
+            log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, ranks reached by the all_reduce %d, visible devices %d, "
+                "(device, pci bus, pci device, pci domain) per rank %s" % (rank, args.gpus, world, rccl_ranks, torch.cuda.device_count(), places))
+            dist.destroy_process_group()
+            sys.exit(5)
     binding.load()
     binding.set_kernel_variant(args.variant)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
@@ -269,10 +376,22 @@ def main():
             prev = us
         return us, done
 
-    def roofline_of(job, launch_us):
+    MALL_BYTES = 256 << 20                 # Infinity Cache (MI355X_MICROARCH.md): a footprint that fits is served from it, not from HBM
+    telemetry = Telemetry(torch, device_index)
+
+    def roofline_of(job, launch_us, clocks=True):
         ach = job.alg_bytes / (launch_us * 1e-6) / 1e9
-        return {"launch_us": round(launch_us, 2), "gpixel_s": round(job.W * job.H / (launch_us * 1e-6) / 1e9, 1),
-                "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)}
+        row = {"launch_us": round(launch_us, 2), "gpixel_s": round(job.W * job.H / (launch_us * 1e-6) / 1e9, 1),
+               "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
+               "footprint_MiB": round(job.alg_bytes / 2 ** 20, 1), "cache_resident": bool(job.alg_bytes <= MALL_BYTES)}
+        if row["cache_resident"]:
+            row["frac_note"] = "blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s)"
+        if clocks:                         # shader clock and board power while this kernel runs back to back (0.15 s, hwmon files)
+            t = telemetry.during(job.step)
+            torch.cuda.synchronize()
+            if t:
+                row.update(t)
+        return row
 
     def pmc_traffic(key):
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -342,6 +461,29 @@ def main():
     # a few hundred launches while the power management reacts, and the `sc1 nt` row stores of round 3 show the same excursion
     # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ... ) -- so a
     # timed region of 20-200 launches right after start-up would measure the excursion, not the kernel.  --no-settle skips it.
+    cold = {}
+    if not args.no_settle:
+        # what a caller who decodes ONE texture sees: the first launch after idle and the mean of the first twenty (an event per launch),
+        # then -- idle again -- the contract's W + K launches started cold (`value_cold`: the measurement of rounds 1 and 2)
+        job.step(); torch.cuda.synchronize()                                 # (the very first launch also loads the code object: not counted)
+        time.sleep(0.3)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        evs[0].record()
+        for k in range(20):
+            job.step()
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        per = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(20)]
+        cold["cold_first_launch_us"] = round(per[0], 2)
+        cold["first_20_mean_us"] = round(sum(per) / 20, 2)
+        time.sleep(0.3)
+        wall_c, launch_ms_c = timed(job, args.steps, args.warmup)
+        image_pixels_c = strong * strong if strong else world * W * H
+        cold["value_cold"] = round(image_pixels_c * args.steps / wall_c / 1e9, 3)
+        cold["ms_per_step_cold"] = round(wall_c / args.steps * 1e3, 5)
+        cold["launch_us_cold"] = round(launch_ms_c * 1e3, 3)
+        cold["note"] = ("started 0.3 s after the previous launch: the first launch, the mean of the first 20 (one HIP event pair each), and the contract's W + K "
+                        "launches without the settling phase that precedes `value`")
     settle_us, settle_launches = (None, 0) if args.no_settle else steady_state_us(job)
     wall, launch_ms = timed(job, args.steps, args.warmup)
     image_pixels = strong * strong if strong else world * W * H
@@ -355,7 +497,35 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified_rows = int(v.item())
 
+    def band_digests_match(f, side, sh, d_out):
+        """this rank's whole band against the compiled reference's digests, eighth by eighth (tests/golden/digests_8192.json bands_all:
+        the 32768^2 images of BC1 and BPTC_FLOAT in eight bands; a band of world N | 8 ranks is 8 / N consecutive eighths).  None where
+        no golden applies."""
+        import hashlib
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "digests_8192.json")))["bands_all"]
+        except Exception:  # noqa
+            return None
+        if side != 32768 or world not in (1, 2, 4, 8) or ("%s/32768/0of8" % f.name) not in gold:
+            return None
+        per = 8 // world
+        ok = True
+        for e in range(sh.rank * per, (sh.rank + 1) * per):
+            g = gold["%s/32768/%dof8" % (f.name, e)]
+            piece = d_out[(e - sh.rank * per) * g["bytes"]:(e - sh.rank * per + 1) * g["bytes"]]
+            ok = ok and hashlib.sha256(piece.cpu().numpy().tobytes()).hexdigest() == g["sha256"]
+        return ok
+
     extras = {}
+    if strong == 32768 and args.stream == "U" and not args.target and args.layout == "linear":
+        mine = band_digests_match(fmt, strong, shard, job.d_out)
+        if mine is not None:
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=coll_dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            extras["whole_band_digests_match_reference_all_ranks"] = bool(flag.item())
+            if not mine:
+                log("bench.py: rank %d: WHOLE-BAND DIGEST MISMATCH against the compiled reference" % rank)
     if world > 1 and not args.no_extras:
         def time_gathers(f, side, sh, band, reps=2):
             """the optional whole-image gather, timed separately from the decode (never part of `value`): to ONE rank with grouped
@@ -409,21 +579,18 @@ def main():
                 j6 = Job(f6, big, (sh6.row1 - sh6.row0) * 4, d6)
                 w6, ms6 = timed(j6, args.steps, max(args.warmup, 10))
                 v6 = j6.verify(16)
-                digest = None
-                if world == 8 and rank == 0 and big == 32768:            # the first band of the image is the golden band of tests/golden/digests_8192.json
-                    import hashlib
-                    try:
-                        want = json.load(open(os.path.join(ROOT, "tests", "golden", "digests_8192.json")))["bands"]["BPTC_FLOAT/32768x4096"]["sha256"]
-                        digest = hashlib.sha256(j6.d_out.cpu().numpy().tobytes()).hexdigest() == want
-                    except Exception as e:  # noqa
-                        digest = repr(e)
+                digest = band_digests_match(f6, big, sh6, j6.d_out)      # EVERY rank digests its whole band (eighths of the golden image)
+                if digest is not None:
+                    dflag = torch.tensor([1 if digest else 0], dtype=torch.int32, device=coll_dev)
+                    dist.all_reduce(dflag, op=dist.ReduceOp.MIN)
+                    digest = bool(dflag.item())
                 v = torch.tensor([v6], dtype=torch.int32, device=coll_dev)
                 dist.all_reduce(v, op=dist.ReduceOp.MIN)
                 row = {"workload": "BPTC_FLOAT->FLOAT_RGBX16, ONE %dx%d image (stream U) sharded by block rows over %d GPU(s): %d rows per GPU, no data-path collective"
                                    % (big, big, world, (sh6.row1 - sh6.row0) * 4),
                        "value_gpixel_s": round(big * big * args.steps / w6 / 1e9, 3), "ms_per_step": round(w6 / args.steps * 1e3, 5), "launch_us": round(ms6 * 1e3, 3),
                        "frac": round(j6.alg_bytes / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "verified_bit_exact_rows_min_over_ranks": int(v.item()),
-                       "rank0_whole_band_digest_matches_reference": digest}
+                       "whole_band_digests_match_reference_all_ranks": digest}
                 row["gather"] = time_gathers(f6, big, sh6, j6.d_out, reps=1)
                 extras["bc6h_32768"] = row
                 del j6
@@ -466,10 +633,16 @@ def main():
         "settle": {"launches_before_warmup": settle_launches, "last_window_us": None if settle_us is None else round(settle_us, 3),
                    "note": "untimed launches before the W warm-up steps, until two 100-launch windows agree within 1.2 % and >= 600 ran (--no-settle: none)"},
     }
-    if verified_rows == 0:
-        log("bench.py: OUTPUT MISMATCH against the oracle")
+    if cold:
+        result["cold"] = cold
+    if verified_rows == 0 or extras.get("whole_band_digests_match_reference_all_ranks") is False:
+        log("bench.py: OUTPUT MISMATCH against the oracle / the reference's band digests")
         result["value"] = 0.0
     if world == 1 and not args.no_extras:
+        t = telemetry.during(job.step)
+        torch.cuda.synchronize()
+        if t:
+            result["roofline"].update(t)
         ref = hbm_reference(job)
         result["roofline"].update(ref)
         write_gbps = job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9
@@ -479,10 +652,19 @@ def main():
             result["roofline"]["frac_of_measured_fill"] = round(write_gbps / best_fill, 4)
         if ref.get("ref_copy_GBps"):
             result["roofline"]["frac_of_measured_copy"] = round(achieved / ref["ref_copy_GBps"], 4)
-    t = pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
-    if t:
-        result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-        result["roofline"]["traffic_source"] = t.get("source")
+    live = None
+    if world == 1 and not args.no_extras and not args.target and W == H and args.stream == "U":
+        live = live_pmc_traffic(fmt.name, W, args.layout)
+    if live:
+        result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+        result["roofline"]["traffic_source"] = live["source"]
+        result["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_bytes", "write_bytes", "profiled_launches")}
+        result["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / job.alg_bytes, 4)
+    else:
+        t = pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
+        if t:
+            result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = "REPLAYED from profiles/pmc_traffic.json (no live counter pass in this run): " + str(t.get("source"))
     if world > 1:
         result["rccl_ranks"] = rccl_ranks
         result["collective_backend"] = backend
@@ -535,23 +717,37 @@ def main():
         if result["roofline"].get("ref_copy_GBps"):     # a mixed read + write stream: beside the 8 TB/s fraction, the fraction of the copy measured in this process
             for row in table.values():
                 row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
-        result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran)",
-                                "seconds": round(time.perf_counter() - t_start, 2), "formats": table}
-        # the headline format beyond the Infinity Cache: 16384^2 = 1 GiB of pixels
-        try:
-            f = F.BY_NAME[args.format]
-            j = Job(f, 16384, 16384, make_input(f, 4096, 4096, "U"))
-            us, launches = steady_state_us(j, window=25, max_windows=8, min_launches=100)
-            row = roofline_of(j, us)
-            row["workload"] = "%s 16384x16384 stream U" % f.name
+        # the six headline formats beyond the Infinity Cache: 16384^2 (1 GiB of 32-bit pixels, 2 GiB of BC6H's)
+        big_table = {}
+        for name in HEADLINE_FORMATS:
+            try:
+                f = F.BY_NAME[name]
+                j = Job(f, 16384, 16384, make_input(f, 4096, 4096, "U"))
+                us, launches = steady_state_us(j, window=25, max_windows=8, min_launches=100)
+                row = roofline_of(j, us)
+                row["launches_before_reading"] = launches
+                big_table["%s/U" % name] = row
+                del j
+            except Exception as e:  # noqa
+                big_table["%s/U" % name] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+        if result["roofline"].get("ref_copy_GBps"):
+            for row in big_table.values():
+                if "achieved_GBps" in row:
+                    row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
+        result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran); "
+                                                             "sclk_mhz / power_w: hwmon samples while the kernel then runs back to back for 0.15 s; cache_resident: "
+                                                             "blocks + pixels <= the 256 MiB Infinity Cache",
+                                "seconds": round(time.perf_counter() - t_start, 2), "formats": table,
+                                "beyond_cache_16384": {"size": "16384x16384", "formats": big_table}}
+        # (the headline format's row of that table under its round-3 name)
+        if "launch_us" in big_table.get("%s/U" % args.format, {}):
+            row = dict(big_table["%s/U" % args.format])
+            row["workload"] = "%s 16384x16384 stream U" % args.format
             best_fill = max(result["roofline"].get(k, 0) for k in ("ref_fill_GBps", "ref_fill_torch_GBps"))
             if best_fill:
-                row["frac_of_measured_fill"] = round(j.blocks * 16 * j.tpx / (us * 1e-6) / 1e9 / best_fill, 4)
+                row["frac_of_measured_fill"] = round(16384 * 16384 * job.tpx / (row["launch_us"] * 1e-6) / 1e9 / best_fill, 4)
             result["beyond_mall"] = row
-            del j
-        except Exception as e:  # noqa
-            log("beyond_mall failed:", e)
-        torch.cuda.empty_cache()
         # this GPU alone on the N > 1 workload (so the driver's scaling curve has a like-for-like N = 1 point)
         try:
             f = F.BY_NAME["BC1"]
@@ -578,9 +774,9 @@ def main():
                 return (time.perf_counter() - t0) / n * 1e6
             api = ol.DetexAPI(binding.LIB_PATH)
             ref_api = ol.load_ref() if ol.have_ref() else None
-            small = {"note": "us per call: detexDecompressTextureLinear(BC1 -> RGBA8, host pointers) and the one-block leaf function; "
-                             "textures up to 1.25 MiB of blocks + pixels are exchanged through pinned host memory (one launch + one "
-                             "synchronisation), larger ones staged through device buffers"}
+            small = {"note": "us per call: detexDecompressTextureLinear(BC1 -> RGBA8, host pointers) and the one-block leaf function, timed from Python "
+                             "through ctypes (`gpu`, `reference_1thread`) and from a compiled C client; textures up to 1.25 MiB of blocks + pixels "
+                             "are exchanged through pinned host memory (one launch, completion polled), larger ones staged through device buffers"}
             f1 = F.BY_NAME["BC1"]
             blk = ol.stream_u(f1, 1, seed=5)
             o16 = np.zeros(64, np.uint8)
@@ -594,6 +790,19 @@ def main():
                     o = np.empty(side * side * 4, np.uint8)
                     row["%dx%d_us" % (side, side)] = round(per_call_us(lambda: a.linear(f1, d, side, side, out=o)), 1)
                 small[label] = row
+            # the same calls from a compiled C program (tests/c_client/detex_client --latency): no ctypes overhead (~3 us per call above)
+            client = os.path.join(ROOT, "tests", "c_client", "detex_client")
+            if os.path.exists(client):
+                import subprocess
+                r = subprocess.run([client, "--latency"], capture_output=True, text=True, timeout=120)
+                cc = {}
+                for line in r.stdout.splitlines():
+                    if line.startswith("latency ") and "=" in line:
+                        k, v = line.split()[1].split("=")
+                        cc[k] = float(v)
+                if cc:
+                    cc["note"] = "median of 2000 calls, compiled C, same library; completion by polling a word the kernel releases in pinned memory"
+                    small["gpu_compiled_c_client"] = cc
             result["host_tier_small"] = small
         except Exception as e:  # noqa
             log("host_tier_small failed:", e)
