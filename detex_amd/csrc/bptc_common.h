@@ -36,6 +36,12 @@ DH uint32_t pk_mad_u16_bhi(uint32_t a, uint32_t b, uint32_t c) {
 	asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
 	return r;
 }
+// ... by the LOW half of b
+DH uint32_t pk_mad_u16_blo(uint32_t a, uint32_t b, uint32_t c) {
+	uint32_t r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
 // per-lane shift amounts (< 16) in the 16-bit lanes of s: v_pk_lshlrev_b16 / v_pk_lshrrev_b16 (vector shifts rather
 // than inline asm, so that compile-time-constant amounts become inline operands instead of VGPRs)
 typedef uint16_t pk_u16x2 __attribute__((ext_vector_type(2)));
@@ -46,6 +52,10 @@ DH uint32_t pk_lshr_v(uint32_t s, uint32_t a) { return of_u16x2(to_u16x2(a) >> t
 #else
 DH uint32_t pk_mad_u16_bhi(uint32_t a, uint32_t b, uint32_t c) {
 	const uint32_t w = b >> 16;
+	return (((a & 0xFFFFu) * w + (c & 0xFFFFu)) & 0xFFFFu) | ((((a >> 16) * w + (c >> 16)) & 0xFFFFu) << 16);
+}
+DH uint32_t pk_mad_u16_blo(uint32_t a, uint32_t b, uint32_t c) {
+	const uint32_t w = b & 0xFFFFu;
 	return (((a & 0xFFFFu) * w + (c & 0xFFFFu)) & 0xFFFFu) | ((((a >> 16) * w + (c >> 16)) & 0xFFFFu) << 16);
 }
 DH uint32_t pk_lshl_v(uint32_t s, uint32_t a) {

@@ -100,9 +100,9 @@ enum Bc7Field : int {
 	F_PIDX0, F_PIDX1, F_PIDX2, F_PIDX3,			// G7  P-bit of endpoint e
 	F_PIDX4, F_PIDX5, F_INS_ONES, F_HIMASK0_C,		// G8  ~0 if the mode has partitions; texel 0's anchor bit (colour stream)
 	F_ROW_C, F_POS_C, F_IBC, F_IMASK_C,			// G9  colour index stream
-	F_WMUL_C, F_WADD_C, F_SEL_BA, F_HALF_A,			// G10 weight = byte 2 of index * mul + add; v_perm selector (colour weight, alpha weight)
-	F_ROW_A2, F_POS_A2, F_IBA, F_IMASK_A,			// G11 alpha index stream (modes 4, 5)
-	F_WMUL_A, F_WADD_A, F_HIMASK0_A, F_PAD,			// G12
+	F_WMUL_C, F_WADD_C, F_SEL_COMB, F_HALF_A,		// G10 weight = byte 2 of index * mul + add; v_perm selector building {colour, alpha} quarter windows
+	F_ROW_A2, F_POS_A2, F_IB4_C, F_IB4_A,			// G11 alpha index stream (modes 4, 5); bits per four texels of either stream
+	F_APAIR, F_IMASK_PAIR, F_HIMASK0_A, F_IB_PAIR,		// G12 the two streams side by side in 16-bit lanes: weight multiplier, index mask, index width
 	kBc7RecWords
 };
 struct alignas(16) Bc7Rec { uint32_t w[kBc7RecWords]; };
@@ -155,13 +155,18 @@ constexpr Bc7Rec bc7_rec(uint32_t mode, bool isel) {
 	L.w[F_WMUL_C] = bptc_weight_mul(ibc); L.w[F_WADD_C] = bptc_weight_add(ibc);
 	L.w[F_HIMASK0_C] = 0xFFFFFFFFu << (ibc - 1u);
 	L.w[F_TWO] = two ? 1u : 0u;
-	L.w[F_ROW_A2] = (pos_a2 >> 5) * kBc7RowBytes; L.w[F_POS_A2] = pos_a2; L.w[F_IBA] = iba; L.w[F_IMASK_A] = (1u << iba) - 1u;
-	L.w[F_WMUL_A] = bptc_weight_mul(iba); L.w[F_WADD_A] = bptc_weight_add(iba);
+	L.w[F_ROW_A2] = (pos_a2 >> 5) * kBc7RowBytes; L.w[F_POS_A2] = pos_a2;
 	L.w[F_HIMASK0_A] = 0xFFFFFFFFu << (iba - 1u);
 	L.w[F_HALF_A] = 8u * iba - 1u;
-	// (colour weight, alpha weight) in 16-bit lanes from byte 2 of the two mads; blocks without a second stream
-	// use the colour weight twice
-	L.w[F_SEL_BA] = two ? 0x0C060C02u : 0x0C020C02u;
+	// Waves that hold a two-stream block (kernel path `any_two`) walk BOTH streams in lockstep, four texels at a time: a quarter
+	// window is {colour indices, alpha indices} in the two 16-bit lanes of one register (4 texels x <= 4 bits each), masked, turned
+	// into the weight pair and advanced by ONE packed instruction each.  Blocks without a second stream carry the colour stream in
+	// both lanes (selector, multiplier, mask and width of the colour stream twice).
+	L.w[F_SEL_COMB] = two ? 0x05040100u : 0x01000100u;			// v_perm(alpha window, colour window, .): low halves side by side
+	L.w[F_IB4_C] = 4u * ibc; L.w[F_IB4_A] = 4u * iba;
+	L.w[F_APAIR] = bptc_weight16_mul(ibc) | (bptc_weight16_mul(two ? iba : ibc) << 16);
+	L.w[F_IMASK_PAIR] = ((1u << ibc) - 1u) | (((1u << (two ? iba : ibc)) - 1u) << 16);
+	L.w[F_IB_PAIR] = ibc | ((two ? iba : ibc) << 16);
 	L.w[F_INS_ONES] = m.ns == 1u ? 0u : 0xFFFFFFFFu;
 	return L;
 }
@@ -432,18 +437,31 @@ DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t flags, uint32_t 
 	// one wave-uniform branch around two straight-line loops (a per-texel branch costs more than it skips)
 	if (any_two) {
 		// alpha stream (modes 4/5: one subset, the only anchor is texel 0)
-		Group g_ai = L.template group<F_ROW_A2 / 4>();	// row_a2, pos_a2, iba, imask_a
-		Group g_aw = L.template group<F_WMUL_A / 4>();	// wmul_a, wadd_a, himask0_a, -
+		Group g_ai = L.template group<F_ROW_A2 / 4>();	// row_a2, pos_a2, ib4_c, ib4_a
+		Group g_aw = L.template group<F_APAIR / 4>();	// apair, imask_pair, himask0_a, ib_pair
 		L.pin(g_ai, g_aw);
 		uint32_t a0, a1;
 		lane.field64(g_ai.x, g_ai.y, a0, a1);
 		uint32_t aw = a0, aw_hi = __builtin_amdgcn_alignbit(a1, a0, g_cw.w);
 		aw += aw & g_aw.z;
-		const uint32_t iba = g_ai.z, imask_a = g_ai.w, wmul_a = g_aw.x, wadd_a = g_aw.y, sel_ba = g_cw.z;
-		// texels in groups: the group's subset rows are requested together, so the wave waits for LDS once per group.  Same
-		// run, three passes each, U / M / C: groups of 1: 54.5 / 56.5 / 48.0 us, of 2: 54.7 / 56.2 / 48.0, of 4: 56.7 / 57.4 /
-		// 47.4 -- the mixed-mode path is better off waiting per texel (its registers are scarce), the uniform-wave copies
-		// (stream C) gain a little from four in flight
+		// Both streams in lockstep (round 4): quarter window q = {colour indices, alpha indices} of texels 4q .. 4q+3 in the 16-bit lanes
+		// of ONE register.  Per texel: one `and` isolates both indices, one v_pk_mad_u16 turns them into both weights scaled by 256
+		// (weight = (index * m + 128) >> 8 with m = 5461 / 2341 / 1092 for 2 / 3 / 4-bit indices: exact, bptc_weight16_mul), one packed
+		// shift drops the scale, one packed shift advances both streams by their own widths -- four instructions for what two separate
+		// streams took seven (and, multiply-add, shift, twice, and a v_perm pairing the weights): 41 -> 34 priced cycles per texel.
+		const uint32_t sel_comb = g_cw.z, apair = g_aw.x, mpair = g_aw.y, ibpair = g_aw.w;
+		uint32_t round128 = 0x00800080u;
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("" : "+v"(round128));		// (VOP3P takes no literal: a VGPR, not an SGPR source at half rate)
+#endif
+		uint32_t comb[4];
+		comb[0] = perm(aw, cw, sel_comb);
+		comb[1] = perm(aw >> g_ai.w, cw >> g_ai.z, sel_comb);
+		comb[2] = perm(aw_hi, cw_hi, sel_comb);
+		comb[3] = perm(aw_hi >> g_ai.w, cw_hi >> g_ai.z, sel_comb);
+		// texels in groups: the group's subset rows are requested together, so the wave waits for LDS once per group.  (Groups of
+		// 1 / 2 / 4 in the mixed-mode path measured 54.5 / 54.7 / 56.7 us on stream U in round 3: it waits per texel, its registers
+		// are scarce; the uniform-wave copies gain a little from four in flight.)
 #pragma unroll
 		for (int i0 = 0; i0 < 16; i0 += kGroup) {
 			uint4 s[kGroup];
@@ -452,12 +470,11 @@ DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t flags, uint32_t 
 #pragma unroll
 			for (int j = 0; j < kGroup; j++) {
 				const int i = i0 + j;
-				if (i == 8) { cw = cw_hi; aw = aw_hi; stage_priority<Tune::kBc7Prio, 2>(); }
-				const uint32_t tc = DETEX_UMUL24(cw & imask_c, wmul_c) + wadd_c;	// weight = byte 2
-				cw >>= ibc;
-				const uint32_t ta = DETEX_UMUL24(aw & imask_a, wmul_a) + wadd_a;
-				aw >>= iba;
-				d[i] = perm(pk_mad_u16(s[j].w, perm(ta, tc, sel_ba), s[j].y), pk_mad_u16_bhi(s[j].z, tc, s[j].x), gather);
+				if (i == 8) stage_priority<Tune::kBc7Prio, 2>();
+				uint32_t &q = comb[i >> 2];
+				const uint32_t w = pk_lshr16(pk_mad_u16(q & mpair, apair, round128), 8);	// {colour weight, alpha weight}
+				if ((i & 3) != 3) q = pk_lshr_v(ibpair, q);
+				d[i] = perm(pk_mad_u16(s[j].w, w, s[j].y), pk_mad_u16_blo(s[j].z, w, s[j].x), gather);
 			}
 		}
 	} else {
@@ -501,17 +518,22 @@ template <bool UNIFORM> struct DecBPTCT {
 	static DH void prepare() { bc7_prepare(); }
 	// 16-byte staging slot of the block-major exchange (kernels.h: decode_blocks) inside this wave's own lane rows, which
 	// are dead once a tile is decoded: vector k (0..3) of the wave's block b (0..63).  Vectors 0-2 live in the wave's
-	// 1 KiB of subset row k, rotated by 2k slots so that the transposed reads (four consecutive lanes = the four vectors
-	// of one block) fall on different banks; vector 3 in the wave's four 256-byte pieces of the block-dword rows.  A
-	// separate 17 KiB staging array left four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
+	// 1 KiB of subset row k, vector 3 in the wave's four 256-byte pieces of the block-dword rows; the slot number is b with
+	// 4k XORed in, so that the transposed reads (four consecutive lanes = the four vectors of one block, sixteen lanes = four
+	// blocks) fall on sixty-four different banks -- and, XOR touching only bits 2-3 of b, a lane's slots for blocks b, b + 16,
+	// b + 32, b + 48 are 256 bytes (vector 3: 1 KiB) apart: one address per lane, the rest immediate offsets (round 3 rotated by
+	// 2k modulo 64: an address computation per read, ~60 VALU per wave in this exchange).  A separate 17 KiB staging array left
+	// four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
 	static constexpr bool kOwnStage = Tune::kBc7OwnStage;
 	static DH void *stage_slot(uint32_t k, uint32_t b) {
 		Bc7Lds &s = bc7_lds();
-		const uint32_t w = threadIdx.x >> 6, p = (b + 2u * k) & 63u;
+		const uint32_t w = threadIdx.x >> 6, p = b ^ (4u * k);
 		char *in_rows = reinterpret_cast<char *>(&s.subset[0][64u * w]) + k * (uint32_t)sizeof(s.subset[0]) + p * 16u;
 		char *in_bits = reinterpret_cast<char *>(&s.bits[0][64u * w]) + (p >> 4) * (uint32_t)sizeof(s.bits[0]) + (p & 15u) * 16u;
 		return k < 3u ? in_rows : in_bits;
 	}
+	// bytes from stage_slot(k, b) to stage_slot(k, b + 16) (b < 48; the XOR leaves bits 4-5 of b alone)
+	static DH uint32_t stage_step(uint32_t k) { return k < 3u ? 256u : (uint32_t)sizeof(bc7_lds().bits[0]); }
 #endif
 	// A block that fails -- reserved mode (decompress-bptc.c:229-237, 361) or, in the checked form, a mode outside
 	// mode_mask / the opaque flags (:363-369) -- is replaced by the mode-6 block whose other bits are all 0: endpoints,

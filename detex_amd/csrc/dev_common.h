@@ -47,6 +47,11 @@ DETEX_HD uint32_t bptc_weight(uint32_t index, uint32_t bits) {
 	const uint32_t magic = bits == 2 ? 21846u : (bits == 3 ? 9363u : 4370u);
 	return (((index << 6) + (d >> 1)) * magic) >> 16;
 }
+// The same weight in 16 bits, for two indices side by side in one register (v_pk_mad_u16): (index * m + 128) >> 8 with
+// m = round(64 * 256 / (2^n - 1)); the product stays below 2^16 and the result equals aWeight2/3/4 for every index
+// (tests/test_host_logic.py proves all 4 + 8 + 16 cases).
+constexpr uint32_t bptc_weight16_mul(uint32_t bits) { return bits == 2 ? 5461u : (bits == 3 ? 2341u : 1092u); }
+
 // signed-RGTC value map [-127,127] -> int16 (decompress-rgtc.c:125-126): (v+127)*65535/254 - 32768
 // 24-bit multiply (v_mul_u32_u24, full rate; a plain 32-bit '*' of unbounded operands is v_mul_lo_u32)
 #if defined(__HIPCC__)

@@ -695,11 +695,42 @@ void decode_blocks(const void *__restrict__ blocks,
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				// A full wave -- every wave but the stream's last -- stores unguarded (`vectors` is wave-uniform: a scalar branch, no
+				// compare and exec-mask update per store); decoders that own the staging slots give a lane's read address once, the
+				// slots of blocks b + 16, b + 32, b + 48 a fixed step further on (Dec::stage_step).
+				if (__builtin_amdgcn_readfirstlane((int)vectors) == 64 * ROW) {
+					if constexpr (OWN) {
+						const char *rd = static_cast<const char *>(Dec::stage_slot(lane % ROW, lane / ROW));
+						const uint32_t step = Dec::stage_step(lane % ROW);
+						v4 staged[GROUP * ROW / 64];			// all reads in flight before the first store (the stores are opaque to the scheduler)
 #pragma unroll
-				for (int j = 0; j < GROUP * ROW / 64; j++) {
-					const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
-					const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
-					if (g < vectors) store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(*slot(e % ROW, e / ROW), out + g);
+						for (int j = 0; j < GROUP * ROW / 64; j++) staged[j] = *reinterpret_cast<const v4 *>(rd + (uint32_t)j * step);
+#pragma unroll
+						for (int j = 0; j < GROUP * ROW / 64; j++)
+							store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(staged[j], out + (uint32_t)j * 64u + lane);
+					} else {
+						// (64-bit pixels keep read-store pairs: with all four reads of a pass in flight before its stores BC6H on coherent
+						// content fell into its slow state -- 80.6 -> 85.9 us on the tiled fixture, same run; profiles/AB_RECORD.md)
+						constexpr bool kReadsFirst = ROW != 8;
+						v4 staged[GROUP * ROW / 64];
+						if constexpr (kReadsFirst) {
+#pragma unroll
+							for (int j = 0; j < GROUP * ROW / 64; j++) { const uint32_t e = (uint32_t)j * 64u + lane; staged[j] = *slot(e % ROW, e / ROW); }
+						}
+#pragma unroll
+						for (int j = 0; j < GROUP * ROW / 64; j++) {
+							const uint32_t e = (uint32_t)j * 64u + lane;
+							if constexpr (!kReadsFirst) staged[j] = *slot(e % ROW, e / ROW);
+							store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(staged[j], out + (uint32_t)p * (GROUP * ROW) + e);
+						}
+					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < GROUP * ROW / 64; j++) {
+						const uint32_t e = (uint32_t)j * 64u + lane;				// vector inside this pass
+						const uint32_t g = (uint32_t)p * (GROUP * ROW) + e;			// vector inside the wave's output
+						if (g < vectors) store_with_policy<PolicyFor<Dec, Tune::kStorePolicyBlocks>::value, 4>(*slot(e % ROW, e / ROW), out + g);
+					}
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();

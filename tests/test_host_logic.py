@@ -79,6 +79,12 @@ extern "C" int check(void) {
 				if (t >> 24 || ((t >> 16) & 0xFFu) != bptc_weight(i, bits)) return 210 + bits;
 			}
 	}
+	// ... and in 16 bits, two indices per register (decode_bptc.h, both index streams in lockstep): (i * m + 128) >> 8, no 16-bit overflow
+	for (uint32_t bits = 2; bits <= 4; bits++)
+		for (uint32_t i = 0; i < (1u << bits); i++) {
+			const uint32_t t = i * bptc_weight16_mul(bits) + 128u;
+			if (t >> 16 || (t >> 8) != bptc_weight(i, bits)) return 220 + bits;
+		}
 	return 0;
 }
 ''')
