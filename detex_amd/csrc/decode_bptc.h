@@ -208,6 +208,7 @@ constexpr Bc7Tables bc7_tables() {
 }
 __constant__ Bc7Tables kBc7Tables = bc7_tables();
 
+// ---- storage: the one part of this decoder that differs between the device and the emulation of tests/host_emul -------------------
 #if defined(__HIPCC__)
 struct Bc7Lds {
 	uint4 subset[3][256];			// per-lane blend operands {base_rg, base_ba, 4*diff_rg, 4*diff_ba}
@@ -228,11 +229,26 @@ DH void bc7_prepare() {
 		reinterpret_cast<u32x4 *>(&bc7_lds().t)[threadIdx.x] = reinterpret_cast<const u32x4 *>(&kBc7Tables)[threadIdx.x];
 	__syncthreads();
 }
-#endif
+// 16-byte staging slot of the block-major exchange (kernels.h: decode_blocks) inside this wave's own lane rows, which
+// are dead once a tile is decoded: vector k (0..3) of the wave's block b (0..63).  Vectors 0-2 live in the wave's
+// 1 KiB of subset row k, vector 3 in the wave's four 256-byte pieces of the block-dword rows; the slot number is b with
+// 4k XORed in, so that the transposed reads (four consecutive lanes = the four vectors of one block, sixteen lanes = four
+// blocks) fall on sixty-four different banks -- and, XOR touching only bits 2-3 of b, a lane's slots for blocks b, b + 16,
+// b + 32, b + 48 are 256 bytes (vector 3: 1 KiB) apart: one address per lane, the rest immediate offsets (round 3 rotated by
+// 2k modulo 64: an address computation per read, ~60 VALU per wave in this exchange).  A separate 17 KiB staging array left
+// four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
+DH void *bc7_stage_slot(uint32_t k, uint32_t b) {
+	Bc7Lds &s = bc7_lds();
+	const uint32_t w = threadIdx.x >> 6, p = b ^ (4u * k);
+	char *in_rows = reinterpret_cast<char *>(&s.subset[0][64u * w]) + k * (uint32_t)sizeof(s.subset[0]) + p * 16u;
+	char *in_bits = reinterpret_cast<char *>(&s.bits[0][64u * w]) + (p >> 4) * (uint32_t)sizeof(s.bits[0]) + (p & 15u) * 16u;
+	return k < 3u ? in_rows : in_bits;
+}
+// bytes from stage_slot(k, b) to stage_slot(k, b + 16) (b < 48; the XOR leaves bits 4-5 of b alone)
+DH uint32_t bc7_stage_step(uint32_t k) { return k < 3u ? 256u : (uint32_t)sizeof(bc7_lds().bits[0]); }
 
-// the per-lane view of that storage; the host emulation (tests/host_emul) keeps it in plain arrays
+// the per-lane view of that storage
 struct Bc7Lane {
-#if defined(__HIPCC__)
 	uint32_t bits_base, subset_base;	// LDS byte addresses of this lane's column
 	uint32_t subset_bits;			// 0x3000 in a VGPR (see get_subset)
 	DH Bc7Lane() {
@@ -240,11 +256,7 @@ struct Bc7Lane {
 		bits_base = (uint32_t)(uintptr_t)&s.bits[0][threadIdx.x];
 		subset_base = (uint32_t)(uintptr_t)&s.subset[0][threadIdx.x];
 		subset_bits = 0x3000u;
-#if defined(__HIP_DEVICE_COMPILE__)
-		// v_bitop3_b32 is VOP3 and takes no literal on gfx950: the compiler would keep the mask in an SGPR, and a full-rate
-		// VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr / bitop3_sgpr)
-		if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(subset_bits));
-#endif
+		if constexpr (Tune::kMasksInVgprs) pin_vgpr(subset_bits);	// (v_bitop3_b32 takes no literal: a VGPR, not an SGPR source at half rate)
 	}
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
 	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -274,23 +286,29 @@ struct Bc7Lane {
 	// byte address of record r in the workgroup's LDS image, opaque to the optimiser: the groups then come as
 	// immediate offsets from one address register
 	static DH uint32_t rec_address(uint32_t r) {
-		uint32_t a = (uint32_t)(uintptr_t)bc7_lds().t.rec + r * (uint32_t)sizeof(Bc7Rec);
-		asm("" : "+v"(a));
-		return a;
+		return opaque((uint32_t)(uintptr_t)bc7_lds().t.rec + r * (uint32_t)sizeof(Bc7Rec));
 	}
 	// group G (four consecutive words) of the record at `address`: ONE ds_read_b128.  pin() keeps such reads whole (the
 	// compiler otherwise narrows a read to ds_read_b96 / ds_read2_b32 when a word is unused: 8 and 4 LDS cycles per wave
 	// instead of 4) and is where the wave waits for them -- so a batch of groups is requested first and pinned together.
 	typedef u32x4 Group;
 	template <int G> static DH Group rec_group(uint32_t address) { return *(const lds_u4 *)(uintptr_t)(address + 16u * G); }
-	static DH void pin(Group &a) { asm volatile("" : "+v"(a)); }
-	static DH void pin(Group &a, Group &b) { asm volatile("" : "+v"(a), "+v"(b)); }
-	static DH void pin(Group &a, Group &b, Group &c, Group &d, Group &e) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)); }
+	static DH void pin(Group &a) { pin_vgpr(a); }
+	static DH void pin(Group &a, Group &b) { pin_vgpr(a, b); }
+	static DH void pin(Group &a, Group &b, Group &c, Group &d, Group &e) { pin_vgpr(a, b, c, d, e); }
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) {
 		return *reinterpret_cast<const Bc7PartEntry *>(reinterpret_cast<const char *>(bc7_lds().t.part) + byte_offset);
 	}
 	static DH uint32_t gather(uint32_t rot) { return bc7_lds().t.gather[rot]; }
+};
 #else
+// THE SAME INTERFACE FOR THE GPU-LESS EMULATION (tests/host_emul): LDS byte addresses held in 32-bit registers do not exist on a
+// host, so the per-lane storage is plain arrays and the workgroup tables are read where they are; everything above and below
+// this block is the code the device runs.
+DH void bc7_prepare() {}
+DH void *bc7_stage_slot(uint32_t, uint32_t) { return nullptr; }
+DH uint32_t bc7_stage_step(uint32_t) { return 0u; }
+struct Bc7Lane {
 	uint32_t bits[6];
 	uint4 subset[3];
 	DH Bc7Lane() { for (int k = 0; k < 6; k++) bits[k] = 0xA5A5A5A5u; }	// rows 4, 5: arbitrary (device: whatever follows in LDS)
@@ -317,8 +335,8 @@ struct Bc7Lane {
 	static DH void pin(Group &, Group &, Group &, Group &, Group &) {}
 	static DH const Bc7PartEntry &part(uint32_t byte_offset) { return kBc7PartTable.e[byte_offset / sizeof(Bc7PartEntry)]; }
 	static DH uint32_t gather(uint32_t rot) { return kBc7Gather[rot]; }
-#endif
 };
+#endif
 
 // FIXED >= 0: the record is a compile-time constant (every lane of the wave is known to use record FIXED)
 template <int FIXED> struct Bc7RecReader {
@@ -451,9 +469,7 @@ DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t flags, uint32_t 
 		// streams took seven (and, multiply-add, shift, twice, and a v_perm pairing the weights): 41 -> 34 priced cycles per texel.
 		const uint32_t sel_comb = g_cw.z, apair = g_aw.x, mpair = g_aw.y, ibpair = g_aw.w;
 		uint32_t round128 = 0x00800080u;
-#if defined(__HIP_DEVICE_COMPILE__)
-		asm volatile("" : "+v"(round128));		// (VOP3P takes no literal: a VGPR, not an SGPR source at half rate)
-#endif
+		pin_vgpr(round128);				// (VOP3P takes no literal: a VGPR, not an SGPR source at half rate)
 		uint32_t comb[4];
 		comb[0] = perm(aw, cw, sel_comb);
 		comb[1] = perm(aw >> g_ai.w, cw >> g_ai.z, sel_comb);
@@ -514,27 +530,11 @@ template <bool UNIFORM> struct DecBPTCT {
 	// (58.8 vs 62.0 us, stream U); with today's 3.6 KiB it is the worse one -- same run, 8192^2, streams U / C: persistent
 	// 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (ab/kernels_persistent.h keeps that kernel for the
 	// measurement build).  The block-major kernel likewise (U / M / C: 62.5-63.3 / 63.8-64.7 / 52.0 vs 64.5 / 66.1 / 47.4).
-#if defined(__HIPCC__)
 	static DH void prepare() { bc7_prepare(); }
-	// 16-byte staging slot of the block-major exchange (kernels.h: decode_blocks) inside this wave's own lane rows, which
-	// are dead once a tile is decoded: vector k (0..3) of the wave's block b (0..63).  Vectors 0-2 live in the wave's
-	// 1 KiB of subset row k, vector 3 in the wave's four 256-byte pieces of the block-dword rows; the slot number is b with
-	// 4k XORed in, so that the transposed reads (four consecutive lanes = the four vectors of one block, sixteen lanes = four
-	// blocks) fall on sixty-four different banks -- and, XOR touching only bits 2-3 of b, a lane's slots for blocks b, b + 16,
-	// b + 32, b + 48 are 256 bytes (vector 3: 1 KiB) apart: one address per lane, the rest immediate offsets (round 3 rotated by
-	// 2k modulo 64: an address computation per read, ~60 VALU per wave in this exchange).  A separate 17 KiB staging array left
-	// four workgroups per CU resident (block-major BC7: 65 us against 58 linear).
+	// the block-major exchange (kernels.h: decode_blocks) stages inside this decoder's own, by then dead, lane rows
 	static constexpr bool kOwnStage = Tune::kBc7OwnStage;
-	static DH void *stage_slot(uint32_t k, uint32_t b) {
-		Bc7Lds &s = bc7_lds();
-		const uint32_t w = threadIdx.x >> 6, p = b ^ (4u * k);
-		char *in_rows = reinterpret_cast<char *>(&s.subset[0][64u * w]) + k * (uint32_t)sizeof(s.subset[0]) + p * 16u;
-		char *in_bits = reinterpret_cast<char *>(&s.bits[0][64u * w]) + (p >> 4) * (uint32_t)sizeof(s.bits[0]) + (p & 15u) * 16u;
-		return k < 3u ? in_rows : in_bits;
-	}
-	// bytes from stage_slot(k, b) to stage_slot(k, b + 16) (b < 48; the XOR leaves bits 4-5 of b alone)
-	static DH uint32_t stage_step(uint32_t k) { return k < 3u ? 256u : (uint32_t)sizeof(bc7_lds().bits[0]); }
-#endif
+	static DH void *stage_slot(uint32_t k, uint32_t b) { return bc7_stage_slot(k, b); }
+	static DH uint32_t stage_step(uint32_t k) { return bc7_stage_step(k); }
 	// A block that fails -- reserved mode (decompress-bptc.c:229-237, 361) or, in the checked form, a mode outside
 	// mode_mask / the opaque flags (:363-369) -- is replaced by the mode-6 block whose other bits are all 0: endpoints,
 	// P-bits and indices 0, which decodes to sixteen zero pixels on the normal path.  A lane-divergent early return made
@@ -551,7 +551,6 @@ template <bool UNIFORM> struct DecBPTCT {
 		const uint32_t keep = cond_to_mask(valid);
 		blk.x = bfi(keep, blk.x, 0x40u); blk.y &= keep; blk.z &= keep; blk.w &= keep;
 		const uint32_t r = bc7_record_index(blk.x);
-#if defined(__HIPCC__)
 		if (UNIFORM && !CHECKED) {
 			const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 			if (__builtin_amdgcn_ballot_w64(r != r0) == 0) {
@@ -568,7 +567,6 @@ template <bool UNIFORM> struct DecBPTCT {
 				}
 			}
 		}
-#endif
 		bc7_decode_with<-1>(blk, r, flags, d);
 		return valid;
 	}

@@ -222,6 +222,8 @@ __constant__ Bc6hPartTable kBc6hPartTable = bc6h_part_table();
 
 // ---- LDS: per-lane blend rows at an aligned base (row address = v_bitop3 of the pre-shifted partition word), the
 // partition table and the mode words; workgroup copies made by prepare() (dev_common.h: prepare_tables)
+// (storage: like decode_bptc.h's, the one part of this decoder that differs between the device and the emulation of tests/host_emul,
+// where LDS byte addresses held in 32-bit registers do not exist: the #else branch keeps the same interface over plain arrays)
 #if defined(__HIPCC__)
 struct Bc6hLds {
 	uint4 row_a[2][256];		// per lane and subset: base r, g, b, diff r		(subset stride 4096: address bit 12)
@@ -277,11 +279,9 @@ struct Bc6hLane {
 		base_a = (uint32_t)(uintptr_t)&s.row_a[0][threadIdx.x];
 		base_b = (uint32_t)(uintptr_t)&s.row_b[0][threadIdx.x];
 		bit12 = 0x1000u; bit11 = 0x800u;
-#if defined(__HIP_DEVICE_COMPILE__)
 		// v_bitop3_b32 is VOP3 (no literal operand on gfx950): left alone the compiler keeps the masks in SGPRs, and a
 		// full-rate VALU op with an SGPR source issues at half rate (tools/ubench/valu_rates.hip: and_sgpr, bitop3_sgpr)
-		if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(bit12), "+v"(bit11));
-#endif
+		if constexpr (Tune::kMasksInVgprs) pin_vgpr(bit12, bit11);
 	}
 	DH void put(int sub, uint4 a, uint2 b) const {
 		((lds_u4 *)(uintptr_t)base_a)[sub * 256] = u32x4{ a.x, a.y, a.z, a.w };
@@ -338,9 +338,7 @@ DH Bc6hParams bc6h_scatter_generic(const Bits128 &b, uint32_t mode, uint32_t fla
 	const Bc6hRoutes routes(mode);
 	const uint32_t pool5 = pool << 5, pool10 = pool << 10;
 	uint32_t bit10 = 1u << 10;			// (not an inline constant: kept in a VGPR, see Bc6hLane::bit12)
-#if defined(__HIP_DEVICE_COMPILE__)
-	if constexpr (Tune::kMasksInVgprs) asm volatile("" : "+v"(bit10));
-#endif
+	if constexpr (Tune::kMasksInVgprs) pin_vgpr(bit10);
 	ep[1][2] = and_or(pool5 >> routes.amount<0>(), 16u, and_or(pool5 >> routes.amount<1>(), 32u, field_at<41, 4>(b)));
 	ep[1][3] = and_or(pool5 >> routes.amount<2>(), 16u, and_or(pool5 >> routes.amount<3>(), 32u, field_at<51, 4>(b)));
 	ep[2][2] = and_or(pool5 >> routes.amount<4>(), 16u, and_or(pool5 >> routes.amount<5>(), 32u, field_at<61, 4>(b)));
@@ -383,12 +381,7 @@ DH Bc6hSignedUnq bc6h_signed_unq(uint32_t epb) {
 	const bool pass = epb >= 16u;
 	return Bc6hSignedUnq{ pass ? 0 : 1, pass ? 0 : -1, pass ? 1u : 17u - epb, pass ? 40000u : lim - 1u, pass ? 0x7FFFFFFFu : 2u * lim - 1u };
 }
-// (inline asm: left to itself the compiler builds the clamp from two compares and two selects)
-#if defined(__HIPCC__)
-DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { int32_t r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
-#else
-DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
-#endif
+DH int32_t bc6h_clamp_sign(int32_t x, int32_t lo, int32_t hi) { return med3_i32(x, lo, hi); }	// (one v_med3_i32: gfx950_prims.h)
 DH int32_t bc6h_unquantize_signed_x4(int32_t x, const Bc6hSignedUnq &k) {
 	const int32_t sign = bc6h_clamp_sign(x, k.neg_unit, k.unit);
 	// (both sides through opaque(): evaluated unconditionally and chosen by a select -- the compiler otherwise branches)
@@ -530,9 +523,7 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 		stage_priority<Tune::kBc6hPrio, 1>();
 		const uint32_t p12 = pe.pmask12, p11 = p12 >> 1;
 		uint32_t b_even = 0, sign_bits = 0x80008000u;
-#if defined(__HIP_DEVICE_COMPILE__)
-		if constexpr (SIGNED && Tune::kMasksInVgprs) asm volatile("" : "+v"(sign_bits));
-#endif
+		if constexpr (SIGNED && Tune::kMasksInVgprs) pin_vgpr(sign_bits);
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
 			if (i == 8) { win = win_hi; stage_priority<Tune::kBc6hPrio, 2>(); }

@@ -38,17 +38,12 @@ __constant__ uint16_t kEacMagnitudes[16] = {
 };
 
 // workgroup copy of the table in LDS (dev_common.h: prepare_tables)
-#if defined(__HIPCC__)
 DH uint16_t *eac_rows_lds() { __shared__ uint16_t rows[16]; return rows; }
 DH void eac_prepare() {
 	if (threadIdx.x < 16u) eac_rows_lds()[threadIdx.x] = kEacMagnitudes[threadIdx.x];
 	__syncthreads();
 }
 DH uint32_t eac_row(uint32_t t) { return eac_rows_lds()[t]; }
-#else
-DH void eac_prepare() {}
-DH uint32_t eac_row(uint32_t t) { return kEacMagnitudes[t]; }
-#endif
 
 
 // Arithmetic of this file runs two signed 16-bit lanes per VGPR (dev_common.h: pk_add16 / pk_sub16 /
@@ -133,7 +128,6 @@ template <uint32_t ALPHA> DH uint32_t etc_planar_texel(const EtcPlanar &c, uint3
 	return EtcGather<ALPHA>::template sat<0>(sat_u8_pk16(pk_ashr16(g, 2)), sat_u8_pk16(pk_ashr16(rb, 2)));
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
 // Planar blocks are rare among other blocks (1 in 36 of a random stream, the smooth patches of real textures), yet a wave
 // with a single one executes the whole 16-texel planar path: ~125 VALU instructions on top of the ~300 of the palette modes.
 // When a wave holds at most eight of them, the owners only derive the six coefficients and park them in LDS; the wave's
@@ -159,8 +153,6 @@ DH bool etc_planar_shared(bool mode_planar, uint64_t &owners) {
 	return owners != 0 && __builtin_popcountll(owners) <= kEtcPlanarShared;
 }
 template <uint32_t ALPHA> DH void etc_planar_wave(bool mode_planar, uint64_t owners, uint32_t W, uint32_t word, uint32_t (&d)[16]) {
-	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 	const uint32_t count = (uint32_t)__builtin_popcountll(owners);
 	EtcPlanarSlab &slab = etc_planar_slab();
 	const uint32_t rank = lanes_below(owners);
@@ -188,7 +180,6 @@ template <uint32_t ALPHA> DH void etc_planar_wave(bool mode_planar, uint64_t own
 	}
 	wave_lds_sync();		// the slab is free again before this wave's next block
 }
-#endif
 
 // KIND: 0 = ETC1, 1 = ETC2, 2 = ETC2 punchthrough.  ALPHA = alpha bits of opaque texels
 // (0xFF000000, or 0 when an EAC alpha plane is merged afterwards).
@@ -229,13 +220,9 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 			if (!(mode_mask & need)) return false;
 		}
 	}
-#if defined(__HIP_DEVICE_COMPILE__)
 	uint64_t planar_owners = 0;
 	const bool planar_shared = KIND != 0 && kEtcPlanarShared > 0 && etc_planar_shared(mode_planar, planar_owners);	// wave-uniform
 	if (mode_planar && !planar_shared) {
-#else
-	if (mode_planar) {
-#endif
 		etc_planar_block<ALPHA>(etc_planar_setup(W, word), d);
 		return true;
 	}
@@ -304,10 +291,8 @@ DH bool etc_colour(uint32_t w0, uint32_t w1, uint32_t mode_mask, uint32_t flags,
 		if (!opaque) { pal0[2] = 0u; pal1[2] = 0u; }
 	}
 	etc_texels(word, flip, pal0, pal1, d);
-#if defined(__HIP_DEVICE_COMPILE__)
 	// the few planar blocks of this wave went through the palette path with meaningless palettes; their texels come now
 	if (KIND != 0 && planar_shared) etc_planar_wave<ALPHA>(mode_planar, planar_owners, W, word, d);
-#endif
 	return true;
 }
 

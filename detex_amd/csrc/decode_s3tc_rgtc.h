@@ -166,7 +166,6 @@ constexpr RgtcSignedTables rgtc_signed_tables() {
 }
 __constant__ RgtcSignedTables kRgtcSignedTables = rgtc_signed_tables();
 static_assert(sizeof(RgtcSignedTables) % 16 == 0, "copied with 16-byte moves");
-#if defined(__HIPCC__)
 DH RgtcSignedTables &rgtc_signed_lds() { __shared__ RgtcSignedTables t; return t; }
 DH void rgtc_signed_prepare() {
 	const uint4 *src = reinterpret_cast<const uint4 *>(&kRgtcSignedTables);
@@ -175,10 +174,6 @@ DH void rgtc_signed_prepare() {
 	__syncthreads();
 }
 DH const RgtcSignedTables &rgtc_signed() { return rgtc_signed_lds(); }
-#else
-DH void rgtc_signed_prepare() {}
-DH const RgtcSignedTables &rgtc_signed() { return kRgtcSignedTables; }
-#endif
 // 16-bit entry at a BYTE offset (offsets are built pre-doubled so that no shift is needed)
 DH uint32_t u16_at(const uint16_t *table, uint32_t byte_offset) {
 	return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(table) + byte_offset);

@@ -175,38 +175,7 @@ template <class Dec, int EPI> DH void prepare_epilogue() {
 	if constexpr (NativeOf<Dec>::value == kNatFloatRGBX16 && EPI >= kEpiToRGBX8) half_lut_prepare();
 }
 
-// A streaming store of 4 / 8 / 12 / 16 bytes with cache policy POLICY: bit 0 = sc0, bit 1 = sc1, bit 2 = nt (gfx940+; sc0 / sc1 are
-// the coherence scope, nt the non-temporal hint).  __builtin_nontemporal_store emits `nt` alone (4).  Measured:
-// without nt the decode kernels lose a quarter (write-allocate in L2 beside the block stream); `sc1 nt` (6) beats plain `nt` by
-// 1-3 % (RGTC1: 15 %) for the kernels with 32-bit and narrower pixels at 8192^2 and 16384^2 and loses 2.7 % for the 64-bit pixels of BC6H.
-// (The compiler has no way to emit these policies, so the instruction is inline asm -- and inline asm is opaque to the hazard
-// recognizer: a VMEM store of more than 8 bytes reads its data registers up to two cycles AFTER it issues, and a VALU instruction
-// must not overwrite them in that window (gfx940: two wait states).  The register allocator reuses a row's registers for the next
-// row's address at once: without the s_nop behind the store a tenth of the first texel rows of BC7 blocks carried eight bytes of
-// pointer, differently on every run; tests/test_gpu_host_multi.py caught it.)
-template <int POLICY, int DWORDS, class V, class P> DH void store_with_policy(V v, P *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-	static_assert(DWORDS >= 1 && DWORDS <= 4, "dword .. dwordx4");
-	if constexpr (POLICY == 4) __builtin_nontemporal_store(v, p);
-	else if constexpr (POLICY == 0) *p = v;
-	else {
-#define DETEXHIP_STORE(BITS) \
-		if constexpr (DWORDS == 1) asm volatile("global_store_dword %0, %1, off " BITS :: "v"(p), "v"(v) : "memory"); \
-		else if constexpr (DWORDS == 2) asm volatile("global_store_dwordx2 %0, %1, off " BITS :: "v"(p), "v"(v) : "memory"); \
-		else if constexpr (DWORDS == 3) asm volatile("global_store_dwordx3 %0, %1, off " BITS "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); \
-		else asm volatile("global_store_dwordx4 %0, %1, off " BITS "\n\ts_nop 1" :: "v"(p), "v"(v) : "memory")
-		if constexpr (POLICY == 1) { DETEXHIP_STORE("sc0"); }
-		else if constexpr (POLICY == 2) { DETEXHIP_STORE("sc1"); }
-		else if constexpr (POLICY == 3) { DETEXHIP_STORE("sc0 sc1"); }
-		else if constexpr (POLICY == 5) { DETEXHIP_STORE("sc0 nt"); }
-		else if constexpr (POLICY == 6) { DETEXHIP_STORE("sc1 nt"); }
-		else { DETEXHIP_STORE("sc0 sc1 nt"); }
-#undef DETEXHIP_STORE
-	}
-#else
-	*p = v;
-#endif
-}
+// (store_with_policy<POLICY, DWORDS>(v, p): a streaming store with an explicit cache policy -- gfx950_prims.h)
 // cache policy of a decoder's stores: DEFAULT (tune.h) unless that is `sc1 nt` and the decoder is one of those the sweep found better
 // off with plain `nt` (Dec::kStorePolicy)
 template <class Dec, int DEFAULT, class = void> struct PolicyFor { static constexpr int value = DEFAULT; };
@@ -253,11 +222,7 @@ template <int ROW> DH void store_row_dword_aligned(uint8_t *dst, const uint32_t 
 }
 
 // measurement builds only: a pause between a wave's row stores (Tune::kStoreSleep, 0 in the product)
-DH void store_pause() {
-#if defined(__HIP_DEVICE_COMPILE__)
-	if constexpr (Tune::kStoreSleep > 0) __builtin_amdgcn_s_sleep(Tune::kStoreSleep);
-#endif
-}
+DH void store_pause() { sleep_cycles64<Tune::kStoreSleep>(); }
 // raise the "some block was invalid" word without an atomic RMW storm (see header comment)
 DH void raise_status(bool bad, uint32_t *status) {
 	if (status == nullptr) return;
@@ -342,10 +307,8 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 // dwords of the word live at one point (an empty asm; no instruction), which keeps the load whole; it is also where
 // the wave waits for the data, so a caller can put work between the request and the pin.
 template <class Word> DH void pin_block(Word &blk) {
-#if defined(__HIPCC__)
-	if constexpr (sizeof(Word) == 16) asm volatile("" : "+v"(blk.x), "+v"(blk.y), "+v"(blk.z), "+v"(blk.w));
-	else asm volatile("" : "+v"(blk.x), "+v"(blk.y));
-#endif
+	if constexpr (sizeof(Word) == 16) pin_vgpr(blk.x, blk.y, blk.z, blk.w);
+	else pin_vgpr(blk.x, blk.y);
 }
 template <class Dec> DH typename BlockWord<Dec::kBlockBytes>::type load_block(const void *blocks, uint32_t i) {
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;

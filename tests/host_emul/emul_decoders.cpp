@@ -2,9 +2,9 @@
 // detex_amd/csrc with g++ (gfx950 builtins emulated by hip_host_shim.h) and exposes a batch
 // entry so tests/test_host_emulation.py can compare the device decode logic with the oracle in
 // this GPU-less container.  Not part of the product; libdetexhip.so never contains this.
-#define DETEXHIP_HOST_EMULATION 1
 #include <string.h>
 #include <type_traits>
+#include "hip_host_shim.h"		// FIRST: the emulated launch environment and gfx950_prims.h in plain C++
 #include "dev_common.h"
 #include "decode_s3tc_rgtc.h"
 #include "decode_etc_eac.h"
@@ -24,6 +24,9 @@ template <class Dec> struct ZeroOnFailure<Dec, typename std::enable_if<Dec::kZer
 
 template <class Dec> static void run(const uint8_t *in, long n, uint32_t mode_mask, uint32_t flags, int checked, uint8_t *out, uint8_t *ok) {
 	constexpr int P = Dec::kPixelBytes;
+	// the workgroup's table copies, made by the decoder's own prepare() as all 256 threads of a workgroup would
+	for (unsigned t = 0; t < 256u; t++) { threadIdx.x = t; prepare_tables<Dec>(); }
+	threadIdx.x = 0;
 	for (long i = 0; i < n; i++) {
 		typename Word<Dec::kBlockBytes>::type blk;
 		memcpy(&blk, in + i * Dec::kBlockBytes, Dec::kBlockBytes);

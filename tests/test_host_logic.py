@@ -3,7 +3,7 @@
 * test_intmath: the multiply-shift divisions / weights of detex_amd/csrc/dev_common.h are
   exhaustively equal to C integer division on the domains of the reference's LUTs.
 * test_device_logic_under_emulation: detex_amd/csrc/decode_*.h compiled with g++ against
-  tests/host_emul/hip_host_shim.h (the six gfx950 builtins emulated) and compared with the
+  tests/host_emul/hip_host_shim.h (amdgcn builtins, one emulated lane, gfx950_prims.h in plain C++) and compared with the
   oracle on every mode-forced class x the mask/flag matrix + random blocks.  This catches logic
   errors in this GPU-less container; it is NOT a parity claim for the hardware path (that is
   tests/test_gpu_parity.py, which has already caught a code-generation problem emulation cannot
