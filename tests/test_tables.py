@@ -81,7 +81,7 @@ def test_bc7_partition_route_table(tmp_path):
     regular one -- checked against a direct computation from the anchor arrays"""
     src = tmp_path / "route.cpp"
     src.write_text(r'''
-#define DETEXHIP_HOST_EMULATION 1
+#include "hip_host_shim.h"
 #include "dev_common.h"
 #include "decode_bptc.h"
 using namespace detexhip;
