@@ -274,8 +274,9 @@ struct WideRowStore {
 		dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
 		store_a = ia < n_blocks; store_b = ib < n_blocks;
 	}
-	// the next texel row of the wave (rows must come in order 0..3); `mine`: this lane has a decoded row to contribute
-	DH void row(bool mine, const uint32_t *o) {
+	// the next texel row of the wave through the transpose (rows must come in order 0..3); `mine`: this lane has a decoded row to
+	// contribute.  Returns the two output vectors this lane stores for the row.
+	DH void exchange(bool mine, const uint32_t *o, v4 &a, v4 &b) {
 		if (mine) {
 			slab[lane] = v4{ o[0], o[1], o[2], o[3] };
 			slab[STRIDE + lane] = v4{ o[4], o[5], o[6], o[7] };
@@ -285,21 +286,36 @@ struct WideRowStore {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const v4 a = slab[src_a], b = slab[src_b];
+		a = slab[src_a]; b = slab[src_b];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+	}
+	DH void store(const v4 &a, const v4 &b) {
 		if (store_a) store_with_policy<Tune::kStorePolicyWide, 4>(a, reinterpret_cast<v4 *>(dst_a));
 		store_pause();
 		if (store_b) store_with_policy<Tune::kStorePolicyWide, 4>(b, reinterpret_cast<v4 *>(dst_b));
 		store_pause();
 		dst_a += pitch; dst_b += pitch;			// (one 64-bit add each; r * pitch came out as two v_mad_u64_u32 per pointer)
 	}
+	DH void row(bool mine, const uint32_t *o) { v4 a, b; exchange(mine, o, a, b); store(a, b); }
 };
 DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks,
 		bool live, const uint32_t (&o)[32]) {
 	WideRowStore st(pixels, pitch, width_in_blocks, first, n_blocks);
+	if constexpr (Tune::kWideBurst) {
+		// all four rows through the transpose first, then the wave's eight stores back to back: a row's stores used to wait for that
+		// row's LDS round trip, which spread the eight stores over the four exchanges -- and the write path wants a wave's stores
+		// in one burst (profiles/AB_RECORD.md: stores spread over a wave's life cost BC6H 13 %).  Register-neutral: a row's eight
+		// result dwords die as its two output vectors are born.
+		WideRowStore::v4 a[4], b[4];
 #pragma unroll
-	for (int r = 0; r < 4; r++) st.row(live, o + 8 * r);
+		for (int r = 0; r < 4; r++) st.exchange(live, o + 8 * r, a[r], b[r]);
+#pragma unroll
+		for (int r = 0; r < 4; r++) st.store(a[r], b[r]);
+	} else {
+#pragma unroll
+		for (int r = 0; r < 4; r++) st.row(live, o + 8 * r);
+	}
 }
 
 // The block of lane i as ONE 8/16-byte load: left to itself the compiler loads the first dword, tests the decoders'

@@ -25,6 +25,8 @@ struct ProductTune {
 	// BC6H linear kernel: texel rows exchanged and stored as the decoder completes them (false: after the whole block -- the
 	// faster way round: DESIGN.md section 5)
 	static constexpr bool kRowWise = false;
+	// 64-bit pixels, linear layout: a wave's four texel rows all exchanged through LDS before its eight stores are issued (one burst)
+	static constexpr bool kWideBurst = true;
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of the formats_*.hip tables, 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
 	static constexpr int kWorkgroupsPerCu = -1;

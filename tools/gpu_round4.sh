@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-4 measurement round on the GPU box (via gpurun): what is committed under profiles/r04/ from the FINAL library comes from here.
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out/round4
+rm -rf $OUT; mkdir -p $OUT
+ROOT=$(pwd)
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s 2>&1 | tail -14 | tee $OUT/pytest_gpu.log
+echo "== bench (driver line, N=1)"; ( time timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; cut -c1-600 $OUT/bench.json
+echo "== compiled C client: fixtures, latency"; tests/c_client/detex_client tests/golden/test-texture-BC1.ktx tests/golden/test-texture-BPTC_FLOAT.ktx | tee $OUT/c_client.txt; tests/c_client/detex_client --latency | tee -a $OUT/c_client.txt
+ldd tests/c_client/detex_client | grep -i "amdhip\|detexhip" >> $OUT/c_client.txt
+echo "== per-format table, all formats, streams U / M / C, linear and tiled"
+timeout 900 python bench.py --no-cpu --no-extras --formats-json $OUT/formats_8192.json > /dev/null 2> $OUT/formats.err; grep -c launch_us $OUT/formats.err
+timeout 900 python bench.py --no-cpu --no-extras --layout tiled --formats-json $OUT/formats_8192_tiled.json > /dev/null 2> $OUT/formats_tiled.err; grep -c launch_us $OUT/formats_tiled.err
+echo "== N=2 plumbing over gloo on this one GPU: the 32768^2 BC1 image in two bands, every rank digests its band (eighths) against the reference"
+DETEX_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --strong-image 32768 --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/bench_n2_gloo_32768.json 2> $OUT/bench_n2_gloo.err; cut -c1-400 $OUT/bench_n2_gloo_32768.json; tail -2 $OUT/bench_n2_gloo.err
+python - <<'PY'
+import json
+try:
+    d = json.loads(open("gpurun_out/round4/bench_n2_gloo_32768.json").read().strip().splitlines()[-1])
+    print("N=2 gloo: value", d["value"], "digests match on all ranks:", d.get("whole_band_digests_match_reference_all_ranks"))
+except Exception as e:
+    print("N=2 gloo line unreadable:", e)
+PY
+echo "== rocprofv3 kernel trace + stats of the bench command (headline); the environment a profiled bench.py sees"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -T -d $ROOT/$OUT/prof_trace -o bc1 --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/prof_trace.log
+cd $ROOT; f=$(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bc1_8192_kernel_stats.csv && head -4 "$f" | cut -c1-160
+python -c "
+import json; d=json.loads(open('$OUT/bench_under_rocprof.json').read().strip().splitlines()[-1]); print('under rocprofv3: traffic_source =', d['roofline'].get('traffic_source','')[:60])"
+bash tools/gpu_rocprof_formats.sh 2>&1 | grep last200 | cut -c1-200; mkdir -p $OUT/rocprof_formats; cp gpurun_out/rocprof_formats/*.json gpurun_out/rocprof_formats/*kernel_stats.csv $OUT/rocprof_formats/ 2>/dev/null
+echo "== PMC traffic (separate passes)"
+timeout 1500 python tools/pmc_traffic.py $OUT BC1:linear BC3:linear BPTC:linear BPTC_FLOAT:linear BPTC_SIGNED_FLOAT:linear ETC2:linear ETC2_EAC:linear BC1:tiled BPTC:tiled 2>&1 | tail -10
+echo "== SQ counters per wave (BC7, signed BC6H)"
+for FMT in BPTC BPTC_SIGNED_FLOAT BPTC_FLOAT; do
+  cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $ROOT/$OUT/sq_$FMT -o sq --output-format csv -- python $ROOT/tools/gpu_run_case.py $FMT U 8192 8192 0 6 linear > /dev/null 2>&1
+  cd $ROOT; f=$(find $OUT/sq_$FMT -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" "$FMT" <<'PY'
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "decode_linear" in r["Kernel_Name"]]
+d = collections.defaultdict(list)
+for r in rows: d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sorted(v)[len(v)//2] for k, v in d.items()}
+w = m.get("SQ_WAVES", 1)
+print(sys.argv[2], "stream U, per wave:", {k: round(v / w, 1) for k, v in m.items() if k != "SQ_WAVES"})
+PY
+  rm -rf $OUT/sq_$FMT
+done | tee $OUT/sq_per_wave.txt
+echo "== small calls"; timeout 300 python tools/gpu_small_latency.py detex_amd/lib/libdetexhip.so 2>/dev/null | tee $OUT/small_latency.jsonl | cut -c1-200
+echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
+echo "== fuzz 45 s"; timeout 300 python tools/gpu_fuzz.py 45 20000 2>&1 | tail -1 | tee $OUT/fuzz.log
+rm -rf $OUT/prof_trace $OUT/pmc_*_*_* 2>/dev/null
+echo "== done"
