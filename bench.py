@@ -350,7 +350,7 @@ def main():
         return wall, ev_ms / steps
 
     def steady_state_us(job, window=100, max_windows=16, tol=0.012, min_launches=600, min_ms=40.0):
-        """launch time once the power-management excursion has passed (20-40 % slower for roughly the 2nd to
+        """launch time once the power-management excursion has passed (profiles/AB_RECORD.md, DESIGN.md section 6: 20-40 % slower for roughly the 2nd to
         12th millisecond after idle -- VALU-heavy kernels and, since round 3, every kernel with `sc1 nt` stores -- then a slow approach
         to the settled clock): windows of launches (>= `window` of them and >= 4 ms each) until two consecutive ones agree within
         `tol` and at least `min_launches` launches and `min_ms` of kernel time have gone by; independent of the driver's --steps /
@@ -459,7 +459,7 @@ def main():
     # Before the contract's W + K launches: run the kernel until its launch time has settled (the same criterion as the per-format
     # table).  The first ~250 launches after idle are not representative of a decode stream -- VALU-heavy kernels slow down for
     # a few hundred launches while the power management reacts, and the `sc1 nt` row stores of round 3 show the same excursion
-    # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ... ) -- so a
+    # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ...) -- so a
     # timed region of 20-200 launches right after start-up would measure the excursion, not the kernel.  --no-settle skips it.
     cold = {}
     if not args.no_settle:

@@ -174,7 +174,7 @@ DH WeightMad weight_mad(uint32_t bits) {
 
 // FIXED_MODE >= 0 instantiates the decoder for one mode with every layout parameter a compile-time
 // constant (used by wave-uniform fast paths); FIXED_MODE = -1 is the per-lane data-driven form.
-// IMPL selects the texel stage (A/B):
+// IMPL selects the texel stage (A/B, profiles/AB_RECORD.md):
 //   0  subset endpoints picked per texel with v_bfi_b32 chains (registers only)
 //   1  subset endpoints kept in per-lane LDS rows, one ds_read_b128 per texel; colour / alpha index
 //      streams (instead of primary / secondary + per-texel swaps); weights by one v_mad_u32_u24

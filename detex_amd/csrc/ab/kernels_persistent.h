@@ -1,4 +1,4 @@
-// ab/kernels_persistent.h -- the linear kernel on a PERSISTENT grid: workgroups decode tiles
+// ab/kernels_persistent.h -- the linear kernel on a PERSISTENT grid (profiles/AB_RECORD.md): workgroups decode tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... on a grid that just fills the chip, the format tables are copied once per
 // resident workgroup and the next tile's block is requested before the current one is decoded.  Measured 1-20 % slower than
 // one workgroup per tile for every format (BC7: 58.3 vs 54.3 us once its tables had shrunk to 3.6 KiB), so the product

@@ -218,7 +218,7 @@ struct Bc7Lds {
 	// they return stands for bits beyond 127, which no field or index ever consumes
 	alignas(16) uint32_t bits[4][256];	// (16-byte aligned: the block-major exchange stages 16-byte vectors here, stage_slot)
 };
-static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU by LDS (the round-2 occupancy sweep padded this struct: DESIGN.md section 5)");
+static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU by LDS (the round-2 occupancy sweep padded this struct: profiles/AB_RECORD.md)");
 DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
 // (Requesting the kernel's first block between the table load and its LDS store -- so that the block travels during the
 // barrier -- was measured too: the compiler issues the block load first either way, and then the barrier waits for the

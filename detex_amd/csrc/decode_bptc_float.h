@@ -402,7 +402,7 @@ DH uint32_t bc6h_sign_magnitude_pk(uint32_t p, uint32_t sign_bits) {
 }
 
 // SWITCH_SCATTER = true keeps the per-mode switch (cheaper when a whole wave shares one mode); the
-// default is the divergence-free scatter (DESIGN.md section 5 has the measured A/B).
+// default is the divergence-free scatter (profiles/AB_RECORD.md has the measured A/B).
 template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8, kNative = SIGNED ? kNatOther : kNatFloatRGBX16;
 	static constexpr int kWavesPerSimd = Tune::kBc6hWavesPerSimd;

@@ -227,7 +227,7 @@ extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_
 // A band pipeline (upload k+1 | kernel k | download k-1 on three streams, uploads from a helper thread because
 // hipMemcpyAsync on pageable memory blocks its caller) was built and measured: 5.40 vs 5.45 ms -- a download that
 // shares the link with an upload runs at 41-50 GB/s instead of 56 and every extra copy call costs 30-50 us
-// (tools/ubench/host_paths.hip, DESIGN.md section 6) -- so it was not kept.
+// (tools/ubench/host_paths.hip, DESIGN.md section 5) -- so it was not kept.
 static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format, bool tiled) {
 	const char *who = tiled ? "detexDecompressTextureTiled" : "detexDecompressTextureLinear";
 	const size_t px = (size_t)detexGetPixelSize(pixel_format);

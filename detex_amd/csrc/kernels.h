@@ -374,7 +374,7 @@ DH bool stores_enabled(const uint32_t *o) {
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
 // One workgroup per tile of 256 consecutive blocks, dispatched by the hardware.  (A persistent grid -- workgroups looping
 // over tiles, tables copied once per resident workgroup, next tile's block prefetched -- measured 1-20 % slower for every
-// format, BC7 included once its tables had shrunk: DESIGN.md section 5; that kernel lives in ab/kernels_persistent.h.)
+// format, BC7 included once its tables had shrunk: profiles/AB_RECORD.md; that kernel lives in ab/kernels_persistent.h.)
 template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 			// while the following rows are still being interpolated -- the 32 result dwords are never all alive (28 VALU operations
 			// fewer per wave), and the wave's eight store instructions are spread over the second half of its life.  That spreading
 			// is the wrong thing to do: 8192^2 BC6H 93.6 / 93.7 / 94.1 us (U / M / C) against 82.8 / 83.3 / 86.2 for the eight stores
-			// in one burst at the end.  Every lane decodes here (those past the end a copy of the last
+			// in one burst at the end (profiles/AB_RECORD.md).  Every lane decodes here (those past the end a copy of the last
 			// block) because every lane stores: output vector e of the wave is written by lane e whoever decoded it.
 			WideRowStore st(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks);
 			const bool ok = Dec::template decode_rows<false>(blk, 0xFFFFFFFFu, decode_flags, [&](int, const uint32_t (&row)[8]) { st.row(true, row); });

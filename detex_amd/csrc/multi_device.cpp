@@ -212,7 +212,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_forma
 
 // Host image in, host image out, over N devices: every shard uploads its band of blocks, decodes it and downloads its band
 // of pixels over ITS OWN PCIe link -- the one lever left for the host-pointer tier, which a single link bounds at ~56 GB/s
-// (8192^2 RGBA8: 4.8 ms of download against 0.04 ms of kernel; DESIGN.md section 6).  One worker thread per shard (copies
+// (8192^2 RGBA8: 4.8 ms of download against 0.04 ms of kernel; DESIGN.md section 5).  One worker thread per shard (copies
 // from and to pageable memory block their caller); the workers use the calling thread's slots, which it does not touch
 // until they have joined.
 extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_format, const void *host_blocks, int width, int height,

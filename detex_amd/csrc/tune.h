@@ -1,4 +1,4 @@
-// tune.h -- the handful of constants the measurement builds of DESIGN.md section 5 vary.
+// tune.h -- the handful of constants the measurement builds of profiles/AB_RECORD.md vary.
 //
 // The product library is compiled with ProductTune, and this file holds the ONLY preprocessor switch of the
 // measurement builds: tools/build_exp_libs.sh writes a small header that derives `Tune` from ProductTune with one or two
@@ -23,14 +23,14 @@ struct ProductTune {
 	static constexpr int kBc6hPrio = 0;
 	static constexpr int kBc6hWavesPerSimd = 0;
 	// BC6H linear kernel: texel rows exchanged and stored as the decoder completes them (false: after the whole block -- the
-	// faster way round: DESIGN.md section 5)
+	// faster way round: profiles/AB_RECORD.md)
 	static constexpr bool kRowWise = false;
 	// 64-bit pixels, linear layout: a wave's four texel rows all exchanged through LDS before its eight stores are issued (one burst)
 	static constexpr bool kWideBurst = true;
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of the formats_*.hip tables, 0 = no cap, 3..7 = this
-	// many for every format (sweeps; the cap is dynamic LDS requested at launch: DESIGN.md section 8)
+	// many for every format (sweeps; the cap is dynamic LDS requested at launch: profiles/AB_RECORD.md)
 	static constexpr int kWorkgroupsPerCu = -1;
-	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate?
+	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store
 	// emits): pixels of up to 32 bits / the 64-bit pixels of BC6H (kernels.h: store_with_policy)

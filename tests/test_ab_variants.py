@@ -1,4 +1,4 @@
-"""Parity of the rejected A/B kernels.  They are NOT part of the product library: build
+"""Parity of the rejected A/B kernels (profiles/AB_RECORD.md).  They are NOT part of the product library: build
 them with `make lib-ab` and run
     DETEXHIP_LIB=build/explib/libdetexhip_ab.so python -m pytest tests/test_ab_variants.py -m gpu
 Without DETEXHIP_LIB pointing at an A/B build this module is skipped."""
@@ -49,7 +49,7 @@ def test_bc1_tile4x4_variant_matches(torch_cuda, oracle):
 
 @pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC", 5), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3), ("BC1", 2), ("BPTC_FLOAT", 2)])
 def test_alternative_decoder_variants_match(name, variant, torch_cuda, oracle, forced_vectors):
-    """the A/B decoder implementations decode identically, forced classes included"""
+    """the A/B decoder implementations (profiles/AB_RECORD.md) decode identically, forced classes included"""
     from detex_amd import binding
     torch = torch_cuda
     fmt = F.BY_NAME[name]

@@ -1,4 +1,4 @@
-"""Reference points for the HBM roofline on this box, and the data-dependence question of DESIGN.md section 8:
+"""Reference points for the HBM roofline on this box, and the data-dependence question of DESIGN.md section 8 / profiles/AB_RECORD.md:
 write-only fills with the decode kernels' store shape (tools/ubench/hbm_ref.hip) for seven data patterns at sizes on both
 sides of the 256 MiB Infinity Cache, non-temporal and ordinary stores, plus 16-byte-vector copies.
 usage: python tools/gpu_hbm_ref.py [out.jsonl]      (one JSON line per measurement, a table on stderr)"""
