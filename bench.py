@@ -124,8 +124,10 @@ class Telemetry:
     """shader clock and package power of the GPU this process decodes on, read from the amdgpu driver's hwmon files (freq1_input in Hz,
     power1_input in microwatts: two small reads, ~20 us) by a sampling thread while a kernel loop runs; None where the files are absent."""
 
-    def __init__(self, torch, device_index):
-        self.dir = None
+    def __init__(self, torch, device_index, hwmon_dir=None):
+        self.dir = hwmon_dir
+        if hwmon_dir is not None:
+            return
         try:
             import glob
             p = torch.cuda.get_device_properties(device_index)

@@ -79,9 +79,18 @@ bool context_ready() {
 	}
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
-	HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
-	HIP_TRY(hipMalloc(&c.d_status, 128), "hipMalloc(status)");
-	HIP_TRY(hipMemset(c.d_status, 0, 128), "hipMemset(status)");
+	auto create = [&]() -> bool {
+		HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
+		HIP_TRY(hipMalloc(&c.d_status, 128), "hipMalloc(status)");
+		HIP_TRY(hipMemset(c.d_status, 0, 128), "hipMemset(status)");
+		return true;
+	};
+	if (!create()) {			// nothing half-made is kept: the next call starts over
+		if (c.d_status) (void)hipFree(c.d_status);
+		if (c.stream) (void)hipStreamDestroy(c.stream);
+		c.d_status = nullptr; c.stream = nullptr;
+		return false;
+	}
 	c.ready = true;
 	return true;
 }
@@ -113,6 +122,7 @@ bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, Direct
 		void *h = nullptr, *d = nullptr;
 		HIP_TRY(hipHostMalloc(&h, rounded, hipHostMallocMapped), "hipHostMalloc");
 		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); detexSetErrorMessage("libdetexhip: hipHostGetDevicePointer failed"); return false; }
+		memset(h, 0, 256);			// status word, ok byte, completion word: a fresh buffer must not hold what looks like a ticket
 		c.h_pin = static_cast<uint8_t *>(h); c.d_pin = static_cast<uint8_t *>(d); c.pin_cap = rounded;
 	}
 	*x = DirectExchange{ c.h_pin, c.d_pin, in_off, out_off };
