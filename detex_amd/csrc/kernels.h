@@ -310,6 +310,15 @@ DH void store_rows_wide_pixels(uint8_t *pixels, uint64_t pitch, uint32_t width_i
 		WideRowStore::v4 a[4], b[4];
 #pragma unroll
 		for (int r = 0; r < 4; r++) st.exchange(live, o + 8 * r, a[r], b[r]);
+		// ... and the four waves of a workgroup start their bursts APART (wave w waits w * kWideStagger * 64 cycles): together they
+		// write 32 KiB into the same four image rows, and on coherent content -- where all four finish decoding in the same cycle --
+		// one after the other is faster: BC6H fixture 84.4-85.3 -> 81.5-82.4 us, random blocks unchanged (82.7-83.6 against 83.1-83.4);
+		// the kernels with pixels up to 32 bits (four stores per wave) gain nothing from the same delay, nor does a stagger at the
+		// start of the kernel (profiles/AB_RECORD.md)
+		if constexpr (Tune::kWideStagger > 0) {
+			const uint32_t w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+			for (uint32_t k = 0; k < w; k++) sleep_cycles64<Tune::kWideStagger>();
+		}
 #pragma unroll
 		for (int r = 0; r < 4; r++) st.store(a[r], b[r]);
 	} else {

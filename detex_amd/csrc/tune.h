@@ -27,6 +27,7 @@ struct ProductTune {
 	static constexpr bool kRowWise = false;
 	// 64-bit pixels, linear layout: a wave's four texel rows all exchanged through LDS before its eight stores are issued (one burst)
 	static constexpr bool kWideBurst = true;
+	static constexpr int kWideStagger = 4;		// ... wave w of the workgroup waiting w * this * 64 cycles before its burst (0 = none)
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of the formats_*.hip tables, 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: profiles/AB_RECORD.md)
 	static constexpr int kWorkgroupsPerCu = -1;

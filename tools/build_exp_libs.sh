@@ -12,6 +12,7 @@
 #   policyN / widepolicyN / blockspolicyN   cache policy of the linear kernels' row stores, pixels up to 32 bits / 64-bit pixels, and of the block-major kernels' stores: bit 0 sc0, bit 1 sc1,
 #                           bit 2 nt (product: 6 = sc1 nt / 4 = nt)
 #   rowwise                 BC6H linear kernel: texel rows exchanged and stored as the decoder completes them
+#   staggerN                64-bit pixels, linear layout: wave w waits w * N * 64 cycles before its store burst (product: 4)
 #   norowburst              64-bit pixels, linear layout: each texel row stored right after its exchange (round 3) instead of all eight stores in one burst
 #   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
 #   sgprconst               v_bitop3 masks left in SGPRs
@@ -43,6 +44,7 @@ for v in "$@"; do
       widepolicy*) body+="static constexpr int kStorePolicyWide = ${k#widepolicy}; " ;;
       policy*) body+="static constexpr int kStorePolicy = ${k#policy}; " ;;
       rowwise) body+="static constexpr bool kRowWise = true; " ;;
+      stagger*) body+="static constexpr int kWideStagger = ${k#stagger}; " ;;
       norowburst) body+="static constexpr bool kWideBurst = false; " ;;
       bc6waves*) body+="static constexpr int kBc6hWavesPerSimd = ${k#bc6waves}; " ;;
       bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;
