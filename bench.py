@@ -255,7 +255,9 @@ def main():
     # DETEX_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (all ranks share
     # cuda:0; a plumbing test, not a measurement).  The driver's runs use RCCL ("nccl").
     backend = os.environ.get("DETEX_BENCH_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    # (a launcher that shows every rank only its own GPU leaves one visible device per process: device 0 is then the rank's)
+    ndev = torch.cuda.device_count()
+    device_index = local_rank if (backend == "nccl" and local_rank < ndev) else local_rank % ndev
     torch.cuda.set_device(device_index)
     rccl_ranks = 1
     if world > 1:
@@ -274,7 +276,10 @@ def main():
         seen = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         places = [tuple(int(v) for v in t.tolist()) for t in seen]
-        if backend == "nccl" and (rccl_ranks != world or args.gpus != world or len(set(places)) != world or world > torch.cuda.device_count()):
+        # distinct GPUs: by PCI address where the runtime reports one, else by device index (which then must not have been folded)
+        by_pci = all(p[1] >= 0 for p in places)
+        distinct = len({p[1:] for p in places}) == world if by_pci else (len({p[0] for p in places}) == world and world <= ndev)
+        if backend == "nccl" and (rccl_ranks != world or args.gpus != world or not distinct):
             log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, ranks reached by the all_reduce %d, visible devices %d, "
                 "(device, pci bus, pci device, pci domain) per rank %s" % (rank, args.gpus, world, rccl_ranks, torch.cuda.device_count(), places))
             dist.destroy_process_group()
