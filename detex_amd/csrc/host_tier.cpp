@@ -128,6 +128,11 @@ bool direct_exchange(ThreadContext &c, size_t in_bytes, size_t out_bytes, Direct
 	*x = DirectExchange{ c.h_pin, c.d_pin, in_off, out_off };
 	return true;
 }
+#if defined(__x86_64__) || defined(__i386__)
+inline void cpu_relax() { __builtin_ia32_pause(); }
+#else
+inline void cpu_relax() {}
+#endif
 constexpr size_t kDoneOffset = 8;		// the completion word inside the exchange buffer's header
 uint32_t next_ticket(ThreadContext &c) { if (++c.ticket == 0u) c.ticket = 1u; return c.ticket; }
 // Spins on the completion word the kernel just launched on c.stream releases.  Every 2^14 polls (a few hundred microseconds) the
@@ -136,7 +141,7 @@ bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket)
 	const uint32_t *word = reinterpret_cast<const uint32_t *>(x.h_base + kDoneOffset);
 	for (uint32_t polls = 1;; polls++) {
 		if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == ticket) return true;
-		__builtin_ia32_pause();
+		cpu_relax();
 		if ((polls & 0x3FFFu) == 0u) {
 			const hipError_t e = hipStreamQuery(c.stream);
 			if (e == hipErrorNotReady) continue;

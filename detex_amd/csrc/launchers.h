@@ -77,9 +77,11 @@ template <auto Kernel> unsigned occupancy_cap_lds(int target) {
 	if (target < 3 || target > 7) return 0u;
 	int device = 0;
 	if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) { (void)hipGetLastError(); return 0u; }
-	static std::atomic<unsigned> cache[64][8];		// request + 1; 0 = not computed yet
-	const unsigned known = cache[device][target].load(std::memory_order_relaxed);
-	if (known) return known - 1u;
+	// per device: (target + 1) << 32 | request -- a kernel is launched with ONE target in practice (its format's table entry), so one
+	// slot per device suffices; another target simply recomputes
+	static std::atomic<uint64_t> cache[64];
+	const uint64_t known = cache[device].load(std::memory_order_relaxed);
+	if ((known >> 32) == (uint64_t)target + 1u) return (unsigned)(known & 0xFFFFFFFFu);
 	unsigned request = 0u;
 	hipFuncAttributes attr{};
 	if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(Kernel)) == hipSuccess) {
@@ -94,7 +96,7 @@ template <auto Kernel> unsigned occupancy_cap_lds(int target) {
 		}
 	}
 	(void)hipGetLastError();
-	cache[device][target].store(request + 1u, std::memory_order_relaxed);
+	cache[device].store(((uint64_t)target + 1u) << 32 | request, std::memory_order_relaxed);
 	return request;
 }
 constexpr int workgroups_per_cu(int per_format) { return Tune::kWorkgroupsPerCu >= 0 ? Tune::kWorkgroupsPerCu : per_format; }
