@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=$1; FMTS=${2:-BPTC}; STREAMS=${3:-U,M,C}
 ROOT=$(pwd); OUT=gpurun_out/r04_$TAG; rm -rf $OUT; mkdir -p $OUT
 python -m pytest tests/test_gpu_parity.py tests/test_quirks.py -m gpu -x -q -k "BPTC or bptc or quirk or fuzz or stream" 2>&1 | tail -3 > $OUT/parity.txt; cat $OUT/parity.txt
-LIBS=ab_libs/libdetexhip_prev.so,detex_amd/lib/libdetexhip.so
+LIBS=${BASE_LIB:-ab_libs/libdetexhip_prev.so},detex_amd/lib/libdetexhip.so
 python tools/gpu_ab.py --libs $LIBS --formats $FMTS --streams $STREAMS --rounds 3 --clocks --out $OUT/ab_linear.jsonl 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
