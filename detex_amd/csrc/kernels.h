@@ -259,7 +259,7 @@ struct WideRowStore {
 	uint32_t lane, src_a, src_b;
 	uint8_t *dst_a, *dst_b;
 	uint64_t pitch;
-	bool store_a, store_b;
+	bool store_a, store_b, full;
 	DH WideRowStore(uint8_t *pixels, uint64_t pitch_, uint32_t width_in_blocks, uint32_t first, uint32_t n_blocks) : pitch(pitch_) {
 		__shared__ v4 xpose[4][STRIDE + 64];
 		slab = xpose[threadIdx.x >> 6];
@@ -268,12 +268,24 @@ struct WideRowStore {
 		// destinations of those two vectors: blocks first + lane/2 and first + 32 + lane/2
 		const uint32_t ia = first + (lane >> 1), ib = ia + 32u;
 		uint32_t by, bx;
-		split_index(ia, width_in_blocks, by, bx);
-		dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
-		split_index(ib, width_in_blocks, by, bx);
-		dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+		// power-of-two widths of at least 64 blocks (kernel-argument uniform: a scalar branch): the wave lies in ONE block row, the
+		// second vector's place is the first one's + 1 KiB -- no second index split, no second 64-bit multiply-add (and the general
+		// path's reciprocal stays out of this one)
+		if ((width_in_blocks & (width_in_blocks - 1u)) == 0u && width_in_blocks >= 64u) {
+			by = ia >> __builtin_ctz(width_in_blocks); bx = ia & (width_in_blocks - 1u);
+			dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+			dst_b = dst_a + 1024;
+		} else {
+			split_index(ia, width_in_blocks, by, bx);
+			dst_a = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+			split_index(ib, width_in_blocks, by, bx);
+			dst_b = pixels + (uint64_t)(by * 4u) * pitch + (uint64_t)bx * 32u + (lane & 1u) * 16u;
+		}
 		store_a = ia < n_blocks; store_b = ib < n_blocks;
+		// every wave but the stream's last stores all of its 128 vectors: a scalar test, unguarded stores
+		full = wave_full(first, n_blocks);
 	}
+	static DH bool wave_full(uint32_t first, uint32_t n_blocks) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)first) + 64u <= n_blocks; }
 	// the next texel row of the wave through the transpose (rows must come in order 0..3); `mine`: this lane has a decoded row to
 	// contribute.  Returns the two output vectors this lane stores for the row.
 	DH void exchange(bool mine, const uint32_t *o, v4 &a, v4 &b) {
@@ -291,9 +303,9 @@ struct WideRowStore {
 		__builtin_amdgcn_wave_barrier();
 	}
 	DH void store(const v4 &a, const v4 &b) {
-		if (store_a) store_with_policy<Tune::kStorePolicyWide, 4>(a, reinterpret_cast<v4 *>(dst_a));
+		if (full || store_a) store_with_policy<Tune::kStorePolicyWide, 4>(a, reinterpret_cast<v4 *>(dst_a));
 		store_pause();
-		if (store_b) store_with_policy<Tune::kStorePolicyWide, 4>(b, reinterpret_cast<v4 *>(dst_b));
+		if (full || store_b) store_with_policy<Tune::kStorePolicyWide, 4>(b, reinterpret_cast<v4 *>(dst_b));
 		store_pause();
 		dst_a += pitch; dst_b += pitch;			// (one 64-bit add each; r * pitch came out as two v_mad_u64_u32 per pointer)
 	}
