@@ -150,6 +150,38 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill_policy(void *d
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// the same 4 KiB per wave written in different SHAPES per store instruction (sc1 nt): 0 = 1 KiB runs (lane j, store k -> vector 64 k + j),
+// 1 = 64-byte pieces 256 B apart (16 (j / 4) + 4 k + j % 4: what a transposition inside quads of lanes gives a block-major kernel),
+// 2 = 16-byte pieces 64 B apart (4 j + k: a lane storing its own block), 3 = 128-byte lines 512 B apart (32 (j / 8) + 8 k + j % 8)
+template <int SHAPE> __global__ __launch_bounds__(256) void fill_shape_kernel(v4 *__restrict__ dst, uint64_t n_vectors, uint32_t seed) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t base = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 256u;
+#pragma unroll
+	for (uint32_t k = 0; k < 4; k++) {
+		const uint32_t o = SHAPE == 0 ? 64u * k + lane : SHAPE == 1 ? 16u * (lane >> 2) + 4u * k + (lane & 3u) : SHAPE == 2 ? 4u * lane + k : 32u * (lane >> 3) + 8u * k + (lane & 7u);
+		const uint64_t i = base + o;
+		if (i < n_vectors) {
+			const v4 v = make_vector<2>((uint32_t)i, seed);
+			asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst + i), "v"(v) : "memory");
+		}
+	}
+}
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_shape(void *dst, size_t bytes, int shape, uint32_t seed, void *stream) {
+	const uint64_t n = bytes / 16u;
+	if (n == 0 || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const dim3 grid((unsigned)((n + 1023u) / 1024u)), block(256);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+	switch (shape) {
+	case 0: hipLaunchKernelGGL((fill_shape_kernel<0>), grid, block, 0, s, d, n, seed); break;
+	case 1: hipLaunchKernelGGL((fill_shape_kernel<1>), grid, block, 0, s, d, n, seed); break;
+	case 2: hipLaunchKernelGGL((fill_shape_kernel<2>), grid, block, 0, s, d, n, seed); break;
+	case 3: hipLaunchKernelGGL((fill_shape_kernel<3>), grid, block, 0, s, d, n, seed); break;
+	default: return 1;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" __attribute__((visibility("default"))) int hbmref_copy(void *dst, const void *src, size_t bytes, int nontemporal, void *stream) {
 	const uint64_t n = bytes / 16u;
 	if (n == 0 || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u)) return 1;
