@@ -25,7 +25,7 @@ tools/ubench/libhbmref.so: tools/ubench/hbm_ref.hip
 # The library's translation units (detex_amd/csrc/host_internal.h lists what each one holds).  Only the .hip files contain device code:
 # one per format family plus the histogram kernels, compiled in parallel (make -j); the .cpp files are host code built by the same driver.
 SRCS_HIP := formats_s3tc_rgtc formats_etc_eac formats_bptc formats_bptc_float histogram
-SRCS_CPP := errors device_tier host_tier multi_device ktx_loader
+SRCS_CPP := errors device_tier host_tier host_resident multi_device ktx_loader
 OBJDIR   := build/obj
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-pass-failed $(EXTRA_HIPFLAGS)
 OBJS     := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(SRCS_HIP) $(SRCS_CPP)))
@@ -60,7 +60,10 @@ tests/host_san/api_san: $(OBJDIR)/api_san_main.o $(OBJS)
 # binary from the SAME source compiled against the REFERENCE's own detex.h -- the client a libdetex user would already have
 REFHDR ?= /root/reference
 CLIENT := tests/c_client/detex_client
-c-client: $(CLIENT) $(if $(wildcard $(REFHDR)/detex.h),$(CLIENT)_refhdr)
+c-client: $(CLIENT) $(if $(wildcard $(REFHDR)/detex.h),$(CLIENT)_refhdr) $(if $(wildcard oracle/_ref/libdetex_ref.so),$(CLIENT)_reflib)
+# the same program over the COMPILED REFERENCE (oracle/_ref, where it has been built): bench.py's like-for-like CPU figure for the small calls
+$(CLIENT)_reflib: $(CLIENT).c include/detex.h oracle/_ref/libdetex_ref.so
+	gcc -std=c99 -O2 -Wall -Wextra -Iinclude -o $@ $< -Loracle/_ref -ldetex_ref -Wl,-rpath,'$$ORIGIN/../../oracle/_ref'
 $(CLIENT): $(CLIENT).c include/detex.h $(LIB)
 	gcc -std=c99 -O2 -Wall -Wextra -Iinclude -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
 $(CLIENT)_refhdr: $(CLIENT).c $(REFHDR)/detex.h $(LIB)
@@ -70,6 +73,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr tools/ubench/valu_rates tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
 .PHONY: all lib lib-ab api-san c-client oracle ubench hbmref clean

@@ -782,8 +782,9 @@ def main():
             api = ol.DetexAPI(binding.LIB_PATH)
             ref_api = ol.load_ref() if ol.have_ref() else None
             small = {"note": "us per call: detexDecompressTextureLinear(BC1 -> RGBA8, host pointers) and the one-block leaf function, timed from Python "
-                             "through ctypes (`gpu`, `reference_1thread`) and from a compiled C client; textures up to 1.25 MiB of blocks + pixels "
-                             "are exchanged through pinned host memory (one launch, completion polled), larger ones staged through device buffers"}
+                             "through ctypes (`gpu`, `reference_1thread`: ~2-3 us of call overhead each) and from a compiled C client; one block and textures of up to "
+                             "1024 blocks go to a resident kernel from the second call in a row on, textures up to 1.25 MiB of blocks + pixels are exchanged "
+                             "through pinned host memory (one launch, completion polled), larger ones staged through device buffers"}
             f1 = F.BY_NAME["BC1"]
             blk = ol.stream_u(f1, 1, seed=5)
             o16 = np.zeros(64, np.uint8)
@@ -801,15 +802,29 @@ def main():
             client = os.path.join(ROOT, "tests", "c_client", "detex_client")
             if os.path.exists(client):
                 import subprocess
-                r = subprocess.run([client, "--latency"], capture_output=True, text=True, timeout=120)
-                cc = {}
-                for line in r.stdout.splitlines():
-                    if line.startswith("latency ") and "=" in line:
-                        k, v = line.split()[1].split("=")
-                        cc[k] = float(v)
+
+                def client_latency(path, env=None):
+                    r = subprocess.run([path, "--latency"], capture_output=True, text=True, timeout=120, env=env)
+                    cc = {}
+                    for line in r.stdout.splitlines():
+                        if line.startswith("latency ") and "=" in line:
+                            k, v = line.split()[1].split("=")
+                            cc[k] = float(v)
+                    return cc
+                cc = client_latency(client)
                 if cc:
-                    cc["note"] = "median of 2000 calls, compiled C, same library; completion by polling a word the kernel releases in pinned memory"
+                    cc["note"] = ("median of 2000 back-to-back calls, compiled C, same library: from the second call on the requests are answered by the resident "
+                                  "kernel (detexhipSetResidentIdleMicroseconds; 256x256 is beyond it: one launch per call, completion polled)")
                     small["gpu_compiled_c_client"] = cc
+                cc = client_latency(client, dict(os.environ, DETEXHIP_RESIDENT_US="0"))
+                if cc:
+                    cc["note"] = "the same with DETEXHIP_RESIDENT_US=0: one launch per call, completion by polling a word the kernel releases in pinned memory"
+                    small["gpu_compiled_c_client_launch_per_call"] = cc
+                if os.path.exists(client + "_reflib"):
+                    cc = client_latency(client + "_reflib")
+                    if cc:
+                        cc["note"] = "the same program linked against the compiled reference (oracle/_ref), one host thread"
+                        small["reference_compiled_c_client"] = cc
             result["host_tier_small"] = small
         except Exception as e:  # noqa
             log("host_tier_small failed:", e)

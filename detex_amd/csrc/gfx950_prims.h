@@ -135,5 +135,16 @@ template <int POLICY, int DWORDS, class V, class P> DH void store_with_policy(V 
 	}
 }
 
+// Four 16-byte loads that go to memory whatever the caches hold (sc0 sc1: system scope), issued back to back and waited for once:
+// the resident kernel's poll of its request line in pinned host memory (kernels_resident.h) -- one round trip across the link.
+DH void load_system_4x16(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+	asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+		"global_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+		"global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\t"
+		"global_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+
 }  // namespace detexhip
 #endif

@@ -9,6 +9,7 @@
 //   histogram.hip            8f-4: mode histogram kernels and their entry points
 //   device_tier.cpp          format lookup, target pixel formats, per-thread settings, the detexhip*Device entry points
 //   host_tier.cpp            the reference's own entry points on host pointers (texture.c:55-145, the 19 leaf decoders)
+//   host_resident.cpp        the resident service kernel behind the smallest of those calls (host side of kernels_resident.h)
 //   multi_device.cpp         one texture over several devices
 //   ktx_loader.cpp           8f-1
 // Only the .hip files contain device code; each instantiates the kernels of its formats and exports one row of launchers per
@@ -51,6 +52,8 @@ struct BatchArgs {
 struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; uint32_t *done; uint32_t ticket; };
 // 8f-3: all levels of a mip chain in one launch (kernels_extra.h: decode_levels)
 struct LevelsArgs { LevelTable table; uint32_t *status; hipStream_t stream; int epi; uint32_t decode_flags; Completion completion; };
+// the resident service kernel of the host tier's smallest calls (kernels_resident.h)
+struct ResidentLaunch { ResidentArgs args; hipStream_t stream; int epi; };
 
 // One row per block format (texture.c:27-48 is the reference's table of decompress functions): the launchers of its kernels.
 struct FormatEntry {
@@ -60,6 +63,7 @@ struct FormatEntry {
 	hipError_t (*blocks)(const BatchArgs &);
 	hipError_t (*single)(const SingleArgs &);
 	hipError_t (*levels)(LevelsArgs &);
+	hipError_t (*service)(const ResidentLaunch &);	// the resident service kernel (kernels_resident.h)
 	int histogram_class;		// kClass... (histogram.hip)
 	const char *kernel_name;
 	int resident;			// resident workgroups per CU of the linear kernels (launchers.h: occupancy_cap_lds); 0 = whatever fits
@@ -92,6 +96,35 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 
 // ---- 8f-4 (histogram.hip) ----------------------------------------------------------------------------------------------------------
 hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first);
+
+// ---- resident service of the host tier's smallest calls (host_resident.cpp; protocol: path_types.h ResidentMail) ---------------------
+// One per host-tier thread context.  All of it runs with the context's device current.
+struct ResidentService {
+	bool ready = false, launched = false, broken = false;
+	const FormatEntry *f = nullptr;		// what the running (or last) instance decodes
+	int epi = 0;
+	uint32_t instance = 0, seq = 0;
+	hipStream_t stream = nullptr;
+	uint8_t *h_buf = nullptr, *d_buf = nullptr;	// [ResidentMail][blocks][pixels], pinned
+	uint32_t *d_words = nullptr;
+	uint64_t ticks_per_us = 100;
+	uint64_t served = 0, started = 0;	// requests answered by resident kernels / instances started (detexhipGetResidentStats)
+	const FormatEntry *prev_f = nullptr;	// the previous small call's pair: the service starts with the second call in a row of one pair
+	int prev_epi = -1;
+	// true if this small call should go through the service (enabled, not broken, the pair repeats, buffers in place); records the pair either way
+	bool wanted(const FormatEntry *fmt, int epilogue);
+	uint8_t *blocks_host();			// where the caller puts the blocks of a kResidentTexture request (kResidentBlockBytes)
+	const uint8_t *pixels_host() const;	// where the pixels of the last request are (kResidentPixelBytes)
+	// posts one request (payload words 0-11 of ResidentMail) and waits for it; *failed = some block was invalid.  false: error message set
+	bool serve(const FormatEntry *fmt, int epilogue, const uint32_t payload[12], bool *failed);
+	void release();
+private:
+	bool prepare(int device);
+	bool launch(uint32_t start_seq);
+	void post(const uint32_t payload[12], uint32_t number);
+	bool stop();
+};
+int resident_idle_microseconds();	// detexhipSetResidentIdleMicroseconds, else DETEXHIP_RESIDENT_US, else 250; 0 = no resident kernels
 
 // ---- host tier <-> multi-device (host_tier.cpp, multi_device.cpp) --------------------------------------------------------------------
 void release_thread_context();

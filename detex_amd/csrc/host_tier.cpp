@@ -27,11 +27,13 @@ struct ThreadContext {
 	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
 	uint8_t *h_pin = nullptr, *d_pin = nullptr;
 	size_t pin_cap = 0;
+	ResidentService service;	// the smallest calls, from the second in a row of one (format, target) pair on (host_resident.cpp)
 	void release() {
 		if (!ready) return;
 		int prev = -1;
 		(void)hipGetDevice(&prev);
 		(void)hipSetDevice(device);
+		service.release();
 		(void)hipStreamSynchronize(stream);
 		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
 		if (h_pin) (void)hipHostFree(h_pin);
@@ -162,6 +164,23 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	if (!scope.ok) return -1;
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
 	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
+	const uint32_t decode_flags = (flags & 0x3FFFFFFFu) | current_spec_flags();
+	{	// from the second call in a row on: a request to the resident kernel instead of a launch
+		const int epi = prepared_epilogue(f->texture_format, pixel_format);
+		if (epi == -2) return -1;
+		if (c.service.wanted(f, epi)) {
+			uint32_t payload[12] = {};
+			memcpy(payload, bitstring, bs);
+			payload[4] = mode_mask; payload[5] = decode_flags; payload[6] = kResidentBlock;
+			bool failed = false;
+			if (c.service.serve(f, epi, payload, &failed)) {
+				if (failed) return 0;
+				memcpy(pixel_buffer, c.service.pixels_host(), out_bytes);
+				return 1;
+			}
+			// (the service has switched itself off with a message; this call still gets its launch)
+		}
+	}
 	DirectExchange x;
 	if (!direct_exchange(c, bs, out_bytes, &x)) return -1;
 	x.h_base[4] = 0;								// the ok byte
@@ -169,7 +188,7 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 		const int epi = prepared_epilogue(f->texture_format, pixel_format);
 		if (epi == -2) return false;
 		const uint32_t ticket = next_ticket(c);
-		SingleArgs a{ bitstring, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi,
+		SingleArgs a{ bitstring, mode_mask, decode_flags, reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi,
 			reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), ticket };
 		HIP_TRY(f->single(a), "kernel launch");
 		return wait_for_ticket(c, x, ticket);
@@ -184,6 +203,11 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 
 namespace detexhip {
 void release_thread_context() { t_ctx.release(); }
+}
+
+extern "C" void detexhipGetResidentStats(unsigned long long *requests, unsigned long long *instances) {
+	if (requests) *requests = t_ctx.service.served;
+	if (instances) *instances = t_ctx.service.started;
 }
 
 extern "C" int detexhipSetDevice(int device) {
@@ -282,7 +306,28 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
 	// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
 	const size_t cov_w = tiled ? 0 : (width < 4u * wb ? width : 4u * wb), cov_h = tiled ? 0 : (height < 4u * hb ? height : 4u * hb);
+	auto copy_out = [&](const uint8_t *res) {
+		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
+		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+	};
 	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
+		// the smallest linear textures, from the second call in a row on: a request to the resident kernel instead of a launch
+		if (!tiled && wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {
+			const int epi = prepared_epilogue(texture->format, pixel_format);
+			if (epi == -2) return false;
+			if (c.service.wanted(f, epi)) {
+				const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(), kResidentTexture };
+				memcpy(c.service.blocks_host(), texture->data, in_bytes);
+				bool failed = false;
+				if (c.service.serve(f, epi, payload, &failed)) {
+					copy_out(c.service.pixels_host());
+					if (failed) detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+					return !failed;
+				}
+			}
+		} else {
+			(void)c.service.wanted(nullptr, -1);		// a larger call ends the row
+		}
 		// small texture: the kernel reads the blocks from, and writes pixels and status into, pinned host memory (direct_exchange)
 		DirectExchange x;
 		if (!direct_exchange(c, in_bytes, out_bytes, &x)) return false;
@@ -308,9 +353,7 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 			HIP_TRY(f->levels(a), "kernel launch");
 			if (!wait_for_ticket(c, x, ticket)) return false;
 		}
-		const uint8_t *res = x.h_base + x.out_off;
-		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
-		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+		copy_out(x.h_base + x.out_off);
 		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
 			detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
 			return false;

@@ -10,6 +10,7 @@
 #include "host_internal.h"
 #include "kernels.h"
 #include "kernels_extra.h"
+#include "kernels_resident.h"
 
 namespace detexhip {
 
@@ -198,12 +199,19 @@ template <class Dec> hipError_t launch_levels(LevelsArgs &a) {
 	return with_epilogue<Dec>(a.epi, [&](auto epi) { return launch_levels_epi<Dec, decltype(epi)::value>(a); });
 }
 
+template <class Dec> hipError_t launch_resident(const ResidentLaunch &r) {
+	return with_epilogue<Dec>(r.epi, [&](auto epi) {
+		hipLaunchKernelGGL((decode_resident<typename PlainDecoder<Dec>::type, decltype(epi)::value>), dim3(kResidentWorkgroups), dim3(256), 0, r.stream, r.args);
+		return hipGetLastError();
+	});
+}
+
 // one row of the format table.  RESIDENT / RESIDENT_BLOCKS: resident workgroups per CU of the linear kernels / of the block-major
 // driver (occupancy_cap_lds), from the sweeps recorded in profiles/AB_RECORD.md (tools/gpu_wg_sweep.sh; 8192^2, streams U / C, caps
 // 3..7 against none): the store-bound kernels with 32-bit or wider pixels and little VALU work gain 1-2.6 % at four or five per CU;
 // BC6H gains 11 % on coherent content at five at the price of 2.6 % on uniform-random blocks; BC7, signed BC6H, ETC2_EAC (linear)
 // and the narrow RGTC1 / EAC_R11 formats lose with any cap and keep what fits.
 #define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
-	&launch_levels<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS }
+	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS }
 
 }  // namespace detexhip

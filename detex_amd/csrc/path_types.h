@@ -47,6 +47,34 @@ struct LevelTable {
 // last one to finish publishes, and zeroes it again for the next launch).
 struct Completion { uint32_t *done; uint32_t *counter; uint32_t ticket; };
 
+// ---- resident service of the host tier's smallest calls (kernels_resident.h, host_resident.cpp) --------------------------------------
+// A launch + its completion cost a host-pointer caller 7.3 us for one block and 10.7 us for a 64x64 texture (the measured floor of a
+// launch per call: profiles/r04/host_tier_latency.txt); a workgroup that is ALREADY RUNNING and polls a request line in pinned host
+// memory answers in 4.2 / 6.4 us (tools/ubench/host_latency.hip: `resident`).  So the second small call in a row of one (format,
+// target) pair starts such a kernel, later ones are posted to it, and it leaves by itself once no request has come for the idle time
+// (detexhipSetResidentIdleMicroseconds; a few hundred microseconds), after announcing that in `state`.
+constexpr uint32_t kResidentWorkgroups = 4;					// textures of up to 4 x 256 blocks (128 x 128 pixels)
+constexpr uint32_t kResidentMaxBlocks = 256u * kResidentWorkgroups;
+constexpr uint32_t kResidentBlockBytes = kResidentMaxBlocks * 16u, kResidentPixelBytes = kResidentMaxBlocks * 16u * 8u;
+enum : uint32_t { kResidentTexture = 0, kResidentBlock = 1, kResidentStop = 2 };	// payload word 6
+enum : uint32_t { kResidentRunning = 1, kResidentExiting = 2, kResidentExited = 3 };	// low two bits of `state`
+// Pinned host memory, 64-byte lines with ONE writing side each.  A request is four 16-byte chunks {request number, three payload
+// words}, each written by the host with one 16-byte store and read by the kernel with one 16-byte load: a request is taken when all
+// four carry the same new number (no ordering between the four reads is assumed).  Payload words: 0-3 the block (kResidentBlock) or
+// width, height, width_in_blocks, height_in_blocks; 4 mode_mask; 5 flags; 6 kind; 7-11 unused.
+struct ResidentMail {
+	uint32_t chunk[4][4];				// host -> device
+	uint32_t done, pad0[15];			// device -> host: number of the last request completed
+	uint32_t state, pad1[15];			// device -> host: instance << 2 | kResident{Running, Exiting, Exited}
+	uint32_t status, pad2[15];			// host zeroes it with a request; the kernel raises it for a failed block
+};
+// `words` (device memory, zeroed once): [0] number of the request the leading workgroup handed to the others, [1] the instance that
+// has left, [2] the workgroups' completion counter, [4..15] that request's payload
+struct ResidentArgs {
+	ResidentMail *mail; const void *blocks; uint8_t *pixels; uint32_t *words;
+	uint32_t start_seq, instance; uint64_t idle_ticks, max_ticks;	// ticks of the constant 100 MHz-class clock (wall_clock64)
+};
+
 // ---- 8f-4: how a format's blocks are classified into modes (histogram.hip: block_mode) -------------------------------------------------
 enum : int { kClassS3TC = 0, kClassS3TCat8, kClassETC1, kClassETC2, kClassETC2PT, kClassETC2at8, kClassBPTC, kClassBPTCFloat, kClassNone };
 

@@ -97,30 +97,40 @@ static int cmp_double(const void *a, const void *b) { const double x = *(const d
 static int latency(void) {
 	enum { N = 2000, WARM = 200 };
 	static double t[N];
-	uint8_t block[8] = { 0x12, 0x34, 0x56, 0x78, 0x9A, 0xBC, 0xDE, 0xF0 }, px[64];
+	uint8_t block[8] = { 0x12, 0x34, 0x56, 0x78, 0x9A, 0xBC, 0xDE, 0xF0 }, px[64], first[64];
+	int wrong = 0;
 	for (int i = -WARM; i < N; i++) {
+		block[4] = (uint8_t)i;					/* another block every call: a stale answer would show */
 		const double t0 = now_us();
 		if (!detexDecompressBlockBC1(block, DETEX_MODE_MASK_ALL, 0, px)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
 		if (i >= 0) t[i] = now_us() - t0;
+		if (i == -WARM) memcpy(first, px, 64);
+		else if (((i + WARM) & 255) == 0 && memcmp(first, px, 64) != 0) wrong++;	/* (block[4] is back at its first value every 256 calls) */
+		else if (((i + WARM) & 255) == 1 && memcmp(first, px, 64) == 0) wrong++;
 	}
 	qsort(t, N, sizeof t[0], cmp_double);
 	printf("latency one_block_us=%.2f p90=%.2f\n", t[N / 2], t[N * 9 / 10]);
-	for (int side = 64; side <= 256; side *= 4) {
-		const size_t nb = (size_t)(side / 4) * (side / 4);
-		uint8_t *blocks = (uint8_t *)malloc(nb * 8), *pixels = (uint8_t *)malloc((size_t)side * side * 4);
+	for (int side = 64; side <= 256; side *= 2) {
+		const size_t nb = (size_t)(side / 4) * (side / 4), out_bytes = (size_t)side * side * 4;
+		uint8_t *blocks = (uint8_t *)malloc(nb * 8), *pixels = (uint8_t *)malloc(out_bytes), *expect = (uint8_t *)malloc(out_bytes);
 		for (size_t k = 0; k < nb * 8; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
 		detexTexture tex;
 		tex.format = DETEX_TEXTURE_FORMAT_BC1; tex.data = blocks; tex.width = side; tex.height = side; tex.width_in_blocks = side / 4; tex.height_in_blocks = side / 4;
 		for (int i = -WARM; i < N; i++) {
+			blocks[4] = (uint8_t)i;
 			const double t0 = now_us();
 			if (!detexDecompressTextureLinear(&tex, pixels, DETEX_PIXEL_FORMAT_RGBA8)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
 			if (i >= 0) t[i] = now_us() - t0;
+			if (i == -WARM) memcpy(expect, pixels, out_bytes);
+			else if (((i + WARM) & 255) == 0 && memcmp(expect, pixels, out_bytes) != 0) wrong++;
+			else if (((i + WARM) & 255) == 1 && memcmp(expect, pixels, 64) == 0) wrong++;
 		}
 		qsort(t, N, sizeof t[0], cmp_double);
 		printf("latency %dx%d_us=%.2f p90=%.2f\n", side, side, t[N / 2], t[N * 9 / 10]);
-		free(blocks); free(pixels);
+		free(blocks); free(pixels); free(expect);
 	}
-	return 0;
+	printf("latency wrong_results=%d\n", wrong);
+	return wrong != 0;
 }
 
 int main(int argc, char **argv) {

@@ -83,3 +83,20 @@ def test_c_client_decodes_the_fixtures_and_a_full_size_stream(built, golden_json
             _, got = _parse(r.stdout.strip().splitlines()[-1])
             want = dg["%s/U" % name]
             assert got["sha256"] == want["sha256"] and (got["ok"] == "1") == want["ok"], (os.path.basename(exe), name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idle_us", ["250", "0", "3", "1"])
+def test_c_client_back_to_back_small_calls(built, idle_us):
+    """2200 one-block calls and 2200 small textures per size in a tight loop from compiled C, another block every call: with the
+    resident kernel answering (default idle time), with a launch per call (0), and with an idle time so short that the kernel keeps
+    leaving between requests (3 us: every way a request can meet a leaving kernel) -- no wrong or stale answer in any of them"""
+    env = dict(_clean_env(), DETEXHIP_RESIDENT_US=idle_us)
+    r = subprocess.run([built[0], "--latency"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = {}
+    for l in r.stdout.splitlines():
+        if l.startswith("latency "):
+            rows.update(_parse(l)[1])
+    assert rows.get("wrong_results") == "0", r.stdout
+    assert all(k in rows for k in ("one_block_us", "64x64_us", "128x128_us", "256x256_us")), r.stdout

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <csetjmp>
+#include <csignal>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -33,6 +35,57 @@ __global__ void work(const uint32_t *in, uint32_t in_dwords, uint4 arg, uint32_t
 	}
 }
 
+// A RESIDENT workgroup instead of a launch per call: thread 0 polls a request word in pinned host memory (system-scope loads across the
+// link), the workgroup does the same work as `work`, releases the request's number in *done and goes back to polling.  It leaves on
+// request 0xFFFFFFFF, after `idle_ticks` of the 100 MHz clock without a request, after `max_ticks` in total, or after `max_polls`
+// polls (three independent bounds: the measurement cannot hang the device).
+__global__ __launch_bounds__(256) void resident(uint32_t *request, uint32_t *done, const uint32_t *in, uint32_t in_dwords, uint32_t *out, uint32_t out_dwords,
+		uint64_t idle_ticks, uint64_t max_ticks, uint64_t max_polls) {
+	__shared__ uint32_t s_seq;
+	uint32_t last = 0;
+	const uint64_t t_start = wall_clock64();
+	uint64_t t_last = t_start, polls = 0;
+	for (;;) {
+		if (threadIdx.x == 0) {
+			uint32_t r;
+			for (;;) {
+				r = __hip_atomic_load(request, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+				if (r != last) break;
+				const uint64_t now = wall_clock64();
+				if (now - t_last > idle_ticks || now - t_start > max_ticks || ++polls > max_polls) { r = 0xFFFFFFFFu; break; }
+			}
+			s_seq = r;
+		}
+		__syncthreads();
+		const uint32_t r = s_seq;
+		__syncthreads();
+		if (r == 0xFFFFFFFFu) break;
+		last = r;
+		const uint32_t seed = in_dwords ? __hip_atomic_load(in + threadIdx.x % in_dwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : r;
+		for (uint32_t k = threadIdx.x; k < out_dwords; k += 256u) out[k] = seed + k;
+		__threadfence_system();
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__hip_atomic_store(done, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			t_last = wall_clock64();
+		}
+	}
+	if (threadIdx.x == 0) __hip_atomic_store(done + 16, 0xE0E0E0E0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);	// "gone"
+}
+
+// can the CPU write fine-grained DEVICE memory directly (large BAR)?  probed under a SIGSEGV handler
+static sigjmp_buf g_probe_jmp;
+static void probe_segv(int) { siglongjmp(g_probe_jmp, 1); }
+static bool cpu_can_write(volatile uint32_t *p) {
+	struct sigaction sa, old_segv, old_bus;
+	memset(&sa, 0, sizeof sa); sa.sa_handler = probe_segv; sigemptyset(&sa.sa_mask);
+	sigaction(SIGSEGV, &sa, &old_segv); sigaction(SIGBUS, &sa, &old_bus);
+	bool ok = false;
+	if (sigsetjmp(g_probe_jmp, 1) == 0) { p[0] = 0x12345678u; ok = p[0] == 0x12345678u; }
+	sigaction(SIGSEGV, &old_segv, nullptr); sigaction(SIGBUS, &old_bus, nullptr);
+	return ok;
+}
+
 struct Stat { double median, mean, p90; };
 template <class F> Stat measure(F &&call, int n = 2000, int warm = 200) {
 	for (int i = 0; i < warm; i++) call();
@@ -44,7 +97,9 @@ template <class F> Stat measure(F &&call, int n = 2000, int warm = 200) {
 }
 
 int main(int argc, char **argv) {
+	setvbuf(stdout, nullptr, _IOLBF, 0);
 	const bool spin = argc > 1 && !strcmp(argv[1], "spin");
+	const bool only_bar = argc > 1 && !strcmp(argv[1], "bar");
 	if (spin) CK(hipSetDeviceFlags(hipDeviceScheduleSpin));
 	CK(hipSetDevice(0));
 	hipStream_t s;
@@ -65,6 +120,7 @@ int main(int argc, char **argv) {
 		{ "one block (16 B argument -> 64 B)", 0, 16, 1 }, { "64x64 BC1 (2 KiB -> 16 KiB)", 512, 4096, 1 }, { "256x256 BC1 (32 KiB -> 256 KiB)", 8192, 65536, 16 } };
 	uint32_t ticket = 0;
 	for (const Case &c : cases) {
+		if (only_bar) break;
 		printf("-- %s\n", c.name);
 		const uint4 arg = { 1, 2, 3, 4 };
 		auto launch = [&](uint32_t *done, uint32_t t) { hipLaunchKernelGGL(work, dim3(c.grid), dim3(256), 0, s, d_in, c.in_dwords, arg, d_out, c.out_dwords, done, t, counter); };
@@ -104,6 +160,79 @@ int main(int argc, char **argv) {
 		}
 		st = measure([&] { memcpy(h + 256, h + (2u << 20), c.in_dwords * 4u); ++ticket; launch(d_done, ticket); while (*h_done != ticket) { __builtin_ia32_pause(); } memcpy(h + (3u << 20), h + (1u << 20), c.out_dwords * 4u); });
 		printf("   poll variant + the two host memcpys           median %6.2f  mean %6.2f  p90 %6.2f us\n", st.median, st.mean, st.p90);
+	}
+	{	// resident workgroup: request word at h + 128, done word at h + 0, "gone" marker at h + 64
+		volatile uint32_t *h_req = reinterpret_cast<volatile uint32_t *>(h + 128);
+		volatile uint32_t *h_gone = reinterpret_cast<volatile uint32_t *>(h + 64);
+		volatile uint32_t *h_in = reinterpret_cast<volatile uint32_t *>(h + 256);
+		volatile uint32_t *h_out = reinterpret_cast<volatile uint32_t *>(h + (1u << 20));
+		for (const Case &c : cases) {
+			if (c.grid != 1) continue;
+			*h_req = 0; *h_done = 0; *h_gone = 0;
+			__sync_synchronize();
+			// bounds: 20 ms idle, 1 s in total, 2^28 polls
+			hipLaunchKernelGGL(resident, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t *>(d + 128), d_done, d_in, c.in_dwords, d_out, c.out_dwords, 2000000ull, 100000000ull, 1ull << 28);
+			uint32_t seq = 0, wrong = 0;
+			Stat st = measure([&] {
+				++seq;
+				if (c.in_dwords) h_in[0] = seq * 7u;
+				__atomic_store_n(const_cast<uint32_t *>(h_req), seq, __ATOMIC_RELEASE);
+				while (*h_done != seq) { __builtin_ia32_pause(); }
+				const uint32_t want = c.in_dwords ? seq * 7u : seq;
+				if (h_out[0] != want || h_out[c.out_dwords - 1] != (c.in_dwords ? h_in[255 % c.in_dwords] : seq) + c.out_dwords - 1) wrong++;
+			});
+			Stat st2 = measure([&] {
+				++seq;
+				memcpy(h + 256, h + (2u << 20), c.in_dwords * 4u);
+				__atomic_store_n(const_cast<uint32_t *>(h_req), seq, __ATOMIC_RELEASE);
+				while (*h_done != seq) { __builtin_ia32_pause(); }
+				memcpy(h + (3u << 20), h + (1u << 20), c.out_dwords * 4u);
+			}, 2000, 0);
+			__atomic_store_n(const_cast<uint32_t *>(h_req), 0xFFFFFFFFu, __ATOMIC_RELEASE);
+			const double t0 = now_us();
+			CK(hipStreamSynchronize(s));
+			printf("-- %s: RESIDENT workgroup, request + completion words in pinned memory\n", c.name);
+			printf("   request -> completion seen by the host          median %6.2f  mean %6.2f  p90 %6.2f us   (wrong results: %u)\n", st.median, st.mean, st.p90, wrong);
+			printf("   ... + the two host memcpys                      median %6.2f  mean %6.2f  p90 %6.2f us\n", st2.median, st2.mean, st2.p90);
+			printf("   stop request -> stream idle %.1f us; gone marker %08x\n", now_us() - t0, *h_gone);
+		}
+	}
+	{	// the same resident workgroup with the request word AND the input in fine-grained device memory that the CPU writes through the BAR
+		int large_bar = 0;
+		(void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, 0);
+		uint8_t *v = nullptr;
+		const hipError_t e = hipExtMallocWithFlags((void **)&v, 1u << 20, hipDeviceMallocFinegrained);
+		printf("-- large BAR attribute %d, hipExtMallocWithFlags(fine-grained) %s\n", large_bar, hipGetErrorString(e));
+		if (e == hipSuccess && cpu_can_write(reinterpret_cast<volatile uint32_t *>(v))) {
+			volatile uint32_t *v_req = reinterpret_cast<volatile uint32_t *>(v + 128);
+			volatile uint32_t *v_in = reinterpret_cast<volatile uint32_t *>(v + 256);
+			volatile uint32_t *h_out = reinterpret_cast<volatile uint32_t *>(h + (1u << 20));
+			for (const Case &c : cases) {
+				if (c.grid != 1) continue;
+				*v_req = 0; *h_done = 0;
+				__sync_synchronize();
+				hipLaunchKernelGGL(resident, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t *>(v + 128), d_done, reinterpret_cast<const uint32_t *>(v + 256), c.in_dwords, d_out, c.out_dwords, 2000000ull, 100000000ull, 1ull << 28);
+				uint32_t seq = 0, wrong = 0;
+				Stat st = measure([&] {
+					++seq;
+					for (uint32_t k = 0; k < c.in_dwords; k++) v_in[k] = seq * 7u + k;		// the whole input through the BAR
+					__builtin_ia32_sfence();			// (the BAR mapping is write-combining: order the input before the request word ...)
+					__atomic_store_n(const_cast<uint32_t *>(v_req), seq, __ATOMIC_RELEASE);
+					__builtin_ia32_sfence();			// (... and push the request word out of the write-combining buffer now)
+					const double t_post = now_us();
+					while (*h_done != seq) { __builtin_ia32_pause(); if (now_us() - t_post > 200000.0) { printf("   no answer to request %u within 0.2 s (done word %u): giving up\n", seq, *h_done); exit(2); } }
+					const uint32_t want = c.in_dwords ? seq * 7u : seq;
+					if (h_out[0] != want) wrong++;
+				});
+				__atomic_store_n(const_cast<uint32_t *>(v_req), 0xFFFFFFFFu, __ATOMIC_RELEASE);
+				CK(hipStreamSynchronize(s));
+				printf("-- %s: RESIDENT workgroup, request + input written by the CPU into device memory (BAR), output + completion in pinned memory\n", c.name);
+				printf("   request -> completion seen by the host          median %6.2f  mean %6.2f  p90 %6.2f us   (wrong results: %u)\n", st.median, st.mean, st.p90, wrong);
+			}
+		} else {
+			printf("   the CPU cannot write that memory: not measured\n");
+		}
+		if (v) (void)hipFree(v);
 	}
 	return 0;
 }
