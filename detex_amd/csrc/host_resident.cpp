@@ -40,7 +40,7 @@ int resident_idle_microseconds() {
 }
 
 bool ResidentService::wanted(const FormatEntry *fmt, int epilogue) {
-	const bool repeat = prev_f == fmt && prev_epi == epilogue;
+	const bool repeat = fmt != nullptr && prev_f == fmt && prev_epi == epilogue;
 	prev_f = fmt; prev_epi = epilogue;
 	if (!repeat || broken || resident_idle_microseconds() <= 0) return false;
 	int device = 0;

@@ -165,28 +165,24 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
 	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
 	const uint32_t decode_flags = (flags & 0x3FFFFFFFu) | current_spec_flags();
-	{	// from the second call in a row on: a request to the resident kernel instead of a launch
-		const int epi = prepared_epilogue(f->texture_format, pixel_format);
-		if (epi == -2) return -1;
-		if (c.service.wanted(f, epi)) {
-			uint32_t payload[12] = {};
-			memcpy(payload, bitstring, bs);
-			payload[4] = mode_mask; payload[5] = decode_flags; payload[6] = kResidentBlock;
-			bool failed = false;
-			if (c.service.serve(f, epi, payload, &failed)) {
-				if (failed) return 0;
-				memcpy(pixel_buffer, c.service.pixels_host(), out_bytes);
-				return 1;
-			}
-			// (the service has switched itself off with a message; this call still gets its launch)
+	const int epi = prepared_epilogue(f->texture_format, pixel_format);
+	if (epi == -2) return -1;
+	if (c.service.wanted(f, epi)) {		// from the second call in a row on: a request to the resident kernel instead of a launch
+		uint32_t payload[12] = {};
+		memcpy(payload, bitstring, bs);
+		payload[4] = mode_mask; payload[5] = decode_flags; payload[6] = kResidentBlock;
+		bool failed = false;
+		if (c.service.serve(f, epi, payload, &failed)) {
+			if (failed) return 0;
+			memcpy(pixel_buffer, c.service.pixels_host(), out_bytes);
+			return 1;
 		}
+		// (the service has switched itself off with a message; this call still gets its launch)
 	}
 	DirectExchange x;
 	if (!direct_exchange(c, bs, out_bytes, &x)) return -1;
 	x.h_base[4] = 0;								// the ok byte
 	auto run = [&]() -> bool {
-		const int epi = prepared_epilogue(f->texture_format, pixel_format);
-		if (epi == -2) return false;
 		const uint32_t ticket = next_ticket(c);
 		SingleArgs a{ bitstring, mode_mask, decode_flags, reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi,
 			reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), ticket };
