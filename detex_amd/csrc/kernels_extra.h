@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void decode_single(const typename BlockWord<De
 	uint32_t o[4 * ROW];
 	const bool ok = decode_word<Dec, EPI, true>(blk, mode_mask, flags, o);
 	if (threadIdx.x == 0) {
+		u32x4 *out = reinterpret_cast<u32x4 *>(pixels);		// (16-byte stores: the buffer is 256-byte aligned, host_tier.cpp: direct_exchange)
 #pragma unroll
-		for (int k = 0; k < 4 * ROW; k++) pixels[k] = o[k];
+		for (int k = 0; k < ROW; k++) out[k] = u32x4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
 		*ok_out = ok ? 1 : 0;
 		if (done) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);	// (release: the stores above are visible to the host first)
 	}

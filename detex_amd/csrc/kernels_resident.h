@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void decode_resident(const ResidentArgs a) {
 			uint32_t o[4 * ROW];
 			const bool ok = decode_word<Dec, EPI, true>(blk, q[4], q[5], o);
 			if (threadIdx.x == 0) {
-				uint32_t *out = reinterpret_cast<uint32_t *>(a.pixels);
+				u32x4 *out = reinterpret_cast<u32x4 *>(a.pixels);		// (16-byte stores: a quarter of the writes across the link)
 #pragma unroll
-				for (int k = 0; k < 4 * ROW; k++) out[k] = o[k];
+				for (int k = 0; k < ROW; k++) out[k] = u32x4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
 				if (!ok) __hip_atomic_store(&a.mail->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		} else {
