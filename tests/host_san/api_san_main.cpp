@@ -104,6 +104,16 @@ int main() {
 	detexhipSetKernelVariant(99); if (detexhipGetKernelVariant() != 0) { printf("variant 99 accepted\n"); g_failures++; }
 	detexhipSetQuirks(0xFFFFFFFFu); if (detexhipGetQuirks() != DETEXHIP_QUIRKS_REFERENCE) { printf("quirk mask not clipped\n"); g_failures++; }
 	detexhipSetQuirks(0); if (detexhipGetQuirks() != 0) { printf("quirk mask not stored\n"); g_failures++; }
+	// the resident service's knob and counters (host_resident.cpp): clamped, previous value returned, NULL pointers accepted
+	{
+		const int before = detexhipSetResidentIdleMicroseconds(-5);
+		if (detexhipSetResidentIdleMicroseconds(2000000000) != 0) { printf("negative idle time not clamped to 0\n"); g_failures++; }
+		if (detexhipSetResidentIdleMicroseconds(before) != 1000000) { printf("idle time not clamped to one second\n"); g_failures++; }
+		unsigned long long served = 1, started = 1;
+		detexhipGetResidentStats(NULL, NULL);
+		detexhipGetResidentStats(&served, &started);
+		if (served != 0 || started != 0) { printf("resident counters of a thread that never decoded are not 0\n"); g_failures++; }
+	}
 	if (detexhipKernelName(0) != nullptr || detexhipKernelName(0xFF000000u) != nullptr || detexhipKernelName(BC1) == nullptr) { printf("detexhipKernelName\n"); g_failures++; }
 	// the conversion-table builder over every half bit pattern (float -> int conversions under UBSan), monotone on [0, 1]
 	unsigned prev = 0;
