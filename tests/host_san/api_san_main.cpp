@@ -7,6 +7,7 @@
 #include "../../include/detexhip.h"
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include <vector>
 
@@ -129,6 +130,40 @@ int main() {
 	detexSetErrorMessage("%%|%c|%5d|%-8s|", 'a', -3, "b");
 	detexhipReleaseThreadResources();
 	detexhipReleaseThreadResources();
+	// WITH a device (the GPU box; tests/test_sanitized_host.py -m gpu): the host tier's real paths under the sanitizers -- the launch
+	// per call, the resident service (requests, a format switch, an idle exit and restart, release while an instance lingers), a staged
+	// texture -- each answer compared with the launch path's answer for the same input
+	if (detexhipGetDeviceCount() > 0) {
+		detexhipSetQuirks(DETEXHIP_QUIRKS_REFERENCE);
+		std::vector<uint8_t> data(1 << 20), want(4 << 20), got(4 << 20);
+		for (size_t k = 0; k < data.size(); k++) data[k] = (uint8_t)(k * 2654435761u >> 11);
+		unsigned long long served0 = 0, served1 = 0;
+		const uint32_t fmts[3] = { DETEX_TEXTURE_FORMAT_BC1, DETEX_TEXTURE_FORMAT_BPTC, DETEX_TEXTURE_FORMAT_BC3 };
+		for (int side = 4; side <= 1024; side *= 4) {
+			for (int f = 0; f < 3; f++) {
+				detexTexture tx = { fmts[f], data.data(), side, side, side / 4, side / 4 };
+				const size_t bytes = (size_t)side * side * 4;
+				detexhipSetResidentIdleMicroseconds(0);			// a launch per call: the answer to compare with
+				const bool ok0 = detexDecompressTextureLinear(&tx, want.data(), RGBA8);
+				detexhipSetResidentIdleMicroseconds(400);
+				for (int rep = 0; rep < 4; rep++) {
+					memset(got.data(), 0xCD, bytes);
+					const bool ok1 = detexDecompressTextureLinear(&tx, got.data(), RGBA8);
+					if (ok0 != ok1 || memcmp(want.data(), got.data(), bytes) != 0) { printf("side %d format %d rep %d: answers differ\n", side, f, rep); g_failures++; }
+					if (rep == 1) { struct timespec ts = { 0, 3000000 }; nanosleep(&ts, nullptr); }	// the instance leaves; the next request starts a new one
+				}
+				uint8_t px_a[64], px_b[64];
+				if (f == 0) for (int rep = 0; rep < 4; rep++) {
+					const bool oa = detexDecompressBlockBC1(data.data() + 8 * rep, DETEX_MODE_MASK_ALL, 0, rep == 0 ? px_a : px_b);
+					if (!oa) { printf("one-block call failed: %s\n", detexGetErrorMessage()); g_failures++; }
+				}
+			}
+		}
+		detexhipGetResidentStats(&served1, nullptr);
+		if (served1 - served0 < 20) { printf("the resident service answered only %llu requests\n", served1 - served0); g_failures++; }
+		detexhipReleaseThreadResources();				// with an instance lingering
+		printf("api_san: device part ran (%llu requests answered by resident kernels)\n", served1 - served0);
+	}
 	printf("api_san: %d problems, no sanitizer report\n", g_failures);
 	return g_failures ? 2 : 0;
 }

@@ -90,3 +90,17 @@ def test_entry_points_refuse_hostile_arguments_under_sanitizers():
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")   # (the HIP runtime keeps its own allocations)
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_host_tier_under_sanitizers_on_the_gpu_box():
+    """the same instrumented binary WITH a device: after the refusals it decodes through the host tier -- a launch per call, the
+    resident service (requests, format switches, idle exits and restarts, release with an instance lingering), staged textures -- and
+    compares every answer with the launch path's; AddressSanitizer / UBSan watch the host code (host_tier.cpp, host_resident.cpp).
+    The binary is built by the CPU suite (`make api-san`) and travels to the GPU box with the tree."""
+    exe = os.path.join(SAN, "api_san")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "api-san"], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout and "device part ran" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
