@@ -145,6 +145,23 @@ DH void load_system_4x16(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) 
 		"s_waitcnt vmcnt(0)"
 		: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
 }
+// The same poll with two more 16-byte loads from a second address (the lane's tagged block chunks), all six in flight together.
+DH void load_system_4x16_and_2x16(const void *p, const void *q, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e, u32x4 &f) {
+	asm volatile("global_load_dwordx4 %0, %6, off sc0 sc1\n\t"
+		"global_load_dwordx4 %1, %6, off offset:16 sc0 sc1\n\t"
+		"global_load_dwordx4 %2, %6, off offset:32 sc0 sc1\n\t"
+		"global_load_dwordx4 %3, %6, off offset:48 sc0 sc1\n\t"
+		"global_load_dwordx4 %4, %7, off sc0 sc1\n\t"
+		"global_load_dwordx4 %5, %7, off offset:16 sc0 sc1\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f) : "v"(p), "v"(q) : "memory");
+}
+DH void load_system_2x16(const void *q, u32x4 &e, u32x4 &f) {
+	asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+		"global_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(e), "=&v"(f) : "v"(q) : "memory");
+}
 
 }  // namespace detexhip
 #endif

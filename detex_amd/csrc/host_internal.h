@@ -113,12 +113,17 @@ struct ResidentService {
 	int prev_epi = -1;
 	// true if this small call should go through the service (enabled, not broken, the pair repeats, buffers in place); records the pair either way
 	bool wanted(const FormatEntry *fmt, int epilogue);
+	// Order of a call: wanted() -> begin() (stops an instance of another pair; gives the request its number) -> blocks into blocks_host()
+	// or tagged with pack_tagged() -> serve().
+	uint32_t begin(const FormatEntry *fmt, int epilogue);	// 0: error message set
 	uint8_t *blocks_host();			// where the caller puts the blocks of a kResidentTexture request (kResidentBlockBytes)
+	void pack_tagged(const void *blocks, size_t bytes, uint32_t number);	// the blocks of a kResidentTagged request (at most 256 blocks)
 	const uint8_t *pixels_host() const;	// where the pixels of the last request are (kResidentPixelBytes)
-	// posts one request (payload words 0-11 of ResidentMail) and waits for it; *failed = some block was invalid.  false: error message set
-	bool serve(const FormatEntry *fmt, int epilogue, const uint32_t payload[12], bool *failed);
+	// posts the request `number` (payload words 0-11 of ResidentMail) and waits for it; *failed = some block was invalid.  false: error message set
+	bool serve(const uint32_t payload[12], uint32_t number, bool *failed);
 	void release();
 private:
+	uint32_t before = 0;			// the number before the one begin() handed out (what a new instance starts from)
 	bool prepare(int device);
 	bool launch(uint32_t start_seq);
 	void post(const uint32_t payload[12], uint32_t number);

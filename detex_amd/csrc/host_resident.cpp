@@ -95,6 +95,7 @@ bool ResidentService::launch(uint32_t start_seq) {
 	l.args.instance = instance;
 	l.args.idle_ticks = (uint64_t)resident_idle_microseconds() * ticks_per_us;
 	l.args.max_ticks = 10000000ull * ticks_per_us;		// ten seconds: a new instance takes over with the next request
+	{ static const char *env = getenv("DETEXHIP_RESIDENT_SPECULATIVE_POLLS"); l.args.speculative_polls = env ? (uint32_t)atoi(env) : 16u; }
 	l.stream = stream; l.epi = epi;
 	__atomic_store_n(&mail->state, instance << 2 | kResidentRunning, __ATOMIC_RELEASE);	// (no instance is running: the line is the host's for now)
 	HIP_TRY(f->service(l), "kernel launch (resident)");
@@ -138,13 +139,34 @@ bool ResidentService::stop() {
 	return true;
 }
 
-bool ResidentService::serve(const FormatEntry *fmt, int epilogue, const uint32_t payload[12], bool *failed) {
-	if (!ready) { detexSetErrorMessage("libdetexhip: resident service used before it was prepared"); return false; }
-	ResidentMail *mail = reinterpret_cast<ResidentMail *>(h_buf);
-	if (launched && (f != fmt || epi != epilogue) && !stop()) return false;
+uint32_t ResidentService::begin(const FormatEntry *fmt, int epilogue) {
+	if (!ready) { detexSetErrorMessage("libdetexhip: resident service used before it was prepared"); return 0u; }
+	if (launched && (f != fmt || epi != epilogue) && !stop()) return 0u;
 	f = fmt; epi = epilogue;
-	const uint32_t before = seq;
+	before = seq;
 	if (++seq == 0u) seq = 1u;
+	return seq;
+}
+
+// 16-byte chunks {eight block bytes, request number, 0}: whatever moment the kernel reads one at, its tag says whose data it is
+void ResidentService::pack_tagged(const void *blocks, size_t bytes, uint32_t number) {
+	const uint8_t *src = static_cast<const uint8_t *>(blocks);
+	uint8_t *dst = blocks_host();
+	for (size_t k = 0; k < bytes / 8u; k++) {
+		uint32_t w[2];
+		memcpy(w, src + 8u * k, 8);
+#if defined(__x86_64__)
+		_mm_store_si128(reinterpret_cast<__m128i *>(dst + 16u * k), _mm_set_epi32(0, (int)number, (int)w[1], (int)w[0]));
+#else
+		typedef uint32_t v4u __attribute__((vector_size(16)));
+		*reinterpret_cast<volatile v4u *>(dst + 16u * k) = v4u{ w[0], w[1], number, 0u };
+#endif
+	}
+}
+
+bool ResidentService::serve(const uint32_t payload[12], uint32_t number, bool *failed) {
+	if (!ready || number != seq) { detexSetErrorMessage("libdetexhip: resident service: serve() without begin()"); return false; }
+	ResidentMail *mail = reinterpret_cast<ResidentMail *>(h_buf);
 	__atomic_store_n(&mail->status, 0u, __ATOMIC_RELAXED);
 	post(payload, seq);
 	if (!launched && !launch(before)) { broken = true; return false; }

@@ -172,7 +172,8 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 		memcpy(payload, bitstring, bs);
 		payload[4] = mode_mask; payload[5] = decode_flags; payload[6] = kResidentBlock;
 		bool failed = false;
-		if (c.service.serve(f, epi, payload, &failed)) {
+		const uint32_t number = c.service.begin(f, epi);
+		if (number != 0u && c.service.serve(payload, number, &failed)) {
 			if (failed) return 0;
 			memcpy(pixel_buffer, c.service.pixels_host(), out_bytes);
 			return 1;
@@ -312,10 +313,17 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 			const int epi = prepared_epilogue(texture->format, pixel_format);
 			if (epi == -2) return false;
 			if (c.service.wanted(f, epi)) {
-				const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(), kResidentTexture };
-				memcpy(c.service.blocks_host(), texture->data, in_bytes);
+				// (up to one tile: the blocks travel as tagged chunks the kernel reads along with its polls -- path_types.h: kResidentTagged)
+				const bool tagged = wb * hb <= 256u;
+				const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(),
+					tagged ? kResidentTagged : kResidentTexture };
 				bool failed = false;
-				if (c.service.serve(f, epi, payload, &failed)) {
+				const uint32_t number = c.service.begin(f, epi);
+				if (number != 0u) {
+					if (tagged) c.service.pack_tagged(texture->data, in_bytes, number);
+					else memcpy(c.service.blocks_host(), texture->data, in_bytes);
+				}
+				if (number != 0u && c.service.serve(payload, number, &failed)) {
 					copy_out(c.service.pixels_host());
 					if (failed) detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
 					return !failed;

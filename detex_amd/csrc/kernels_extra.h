@@ -49,15 +49,15 @@ DH void publish_completion(const Completion &c) {
 	}
 }
 
-// one workgroup's 256 blocks of one level
-template <class Dec, int EPI> DH void decode_level_tile(const LevelDesc &lv, uint32_t i, uint32_t *__restrict__ status, uint32_t decode_flags) {
+// one workgroup's 256 blocks of one level; `fetch(i)` delivers block i (from the level's stream, or a word the caller already holds)
+template <class Dec, int EPI, class Fetch> DH void decode_level_tile_from(const LevelDesc &lv, uint32_t i, uint32_t *__restrict__ status, uint32_t decode_flags, Fetch &&fetch) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	if constexpr (ROW == 8) {
 		if (lv.fast) {		// workgroup-uniform (a workgroup never spans two levels): 64-bit pixels leave through the LDS transpose
 			const bool live = i < lv.n_blocks;
 			uint32_t o[4 * ROW];
 			bool ok = true;
-			if (live) ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, decode_flags, o);
+			if (live) ok = decode_word<Dec, EPI, false>(fetch(i), 0xFFFFFFFFu, decode_flags, o);
 			store_rows_wide_pixels(lv.pixels, lv.pitch, lv.width_in_blocks, i - (threadIdx.x & 63u), lv.n_blocks, live, o);
 			if (live) raise_status(!ok, status);
 			return;
@@ -65,7 +65,7 @@ template <class Dec, int EPI> DH void decode_level_tile(const LevelDesc &lv, uin
 	}
 	if (i >= lv.n_blocks) return;
 	uint32_t o[4 * ROW];
-	const bool ok = decode_block<Dec, EPI, false>(lv.blocks, i, 0xFFFFFFFFu, decode_flags, o);
+	const bool ok = decode_word<Dec, EPI, false>(fetch(i), 0xFFFFFFFFu, decode_flags, o);
 	uint32_t by, bx;
 	split_index(i, lv.width_in_blocks, by, bx);
 	uint8_t *dst = lv.pixels + (uint64_t)(by * 4u) * lv.pitch + (uint64_t)bx * (4u * ROW);
@@ -82,6 +82,9 @@ template <class Dec, int EPI> DH void decode_level_tile(const LevelDesc &lv, uin
 		}
 	}
 	raise_status(!ok, status);
+}
+template <class Dec, int EPI> DH void decode_level_tile(const LevelDesc &lv, uint32_t i, uint32_t *__restrict__ status, uint32_t decode_flags) {
+	decode_level_tile_from<Dec, EPI>(lv, i, status, decode_flags, [&](uint32_t k) { return load_block<Dec>(lv.blocks, k); });
 }
 
 // Also the kernel of the host tier's small textures (one level, blocks and pixels in pinned host memory): `completion` then names the

@@ -56,12 +56,16 @@ struct Completion { uint32_t *done; uint32_t *counter; uint32_t ticket; };
 constexpr uint32_t kResidentWorkgroups = 4;					// textures of up to 4 x 256 blocks (128 x 128 pixels)
 constexpr uint32_t kResidentMaxBlocks = 256u * kResidentWorkgroups;
 constexpr uint32_t kResidentBlockBytes = kResidentMaxBlocks * 16u, kResidentPixelBytes = kResidentMaxBlocks * 16u * 8u;
-enum : uint32_t { kResidentTexture = 0, kResidentBlock = 1, kResidentStop = 2 };	// payload word 6
+enum : uint32_t { kResidentTexture = 0, kResidentBlock = 1, kResidentStop = 2, kResidentTagged = 3 };	// payload word 6
 enum : uint32_t { kResidentRunning = 1, kResidentExiting = 2, kResidentExited = 3 };	// low two bits of `state`
 // Pinned host memory, 64-byte lines with ONE writing side each.  A request is four 16-byte chunks {request number, three payload
 // words}, each written by the host with one 16-byte store and read by the kernel with one 16-byte load: a request is taken when all
 // four carry the same new number (no ordering between the four reads is assumed).  Payload words: 0-3 the block (kResidentBlock) or
 // width, height, width_in_blocks, height_in_blocks; 4 mode_mask; 5 flags; 6 kind; 7-11 unused.
+// kResidentTagged = a texture of at most 256 blocks whose blocks the host has laid out as 16-byte chunks {eight block bytes, request
+// number, 0}, too (one chunk per 8-byte block, two per 16-byte block): the leading workgroup reads its lanes' chunks WITH every poll
+// of the request line, and a chunk that carries the request's number is that request's data whenever it was read -- so the second
+// round trip across the link (request seen, then blocks fetched) is saved; chunks with another number are simply read again.
 struct ResidentMail {
 	uint32_t chunk[4][4];				// host -> device
 	uint32_t done, pad0[15];			// device -> host: number of the last request completed
@@ -73,6 +77,7 @@ struct ResidentMail {
 struct ResidentArgs {
 	ResidentMail *mail; const void *blocks; uint8_t *pixels; uint32_t *words;
 	uint32_t start_seq, instance; uint64_t idle_ticks, max_ticks;	// ticks of the constant 100 MHz-class clock (wall_clock64)
+	uint32_t speculative_polls;					// polls after a tagged request during which the leader's lanes read their chunks too
 };
 
 // ---- 8f-4: how a format's blocks are classified into modes (histogram.hip: block_mode) -------------------------------------------------
