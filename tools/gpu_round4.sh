@@ -8,6 +8,9 @@ ROOT=$(pwd)
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s 2>&1 | tail -14 | tee $OUT/pytest_gpu.log
 echo "== bench (driver line, N=1)"; ( time timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; cut -c1-600 $OUT/bench.json
 echo "== compiled C client: fixtures, latency"; tests/c_client/detex_client tests/golden/test-texture-BC1.ktx tests/golden/test-texture-BPTC_FLOAT.ktx | tee $OUT/c_client.txt; tests/c_client/detex_client --latency | tee -a $OUT/c_client.txt
+echo "-- the same with DETEXHIP_RESIDENT_US=0 (a launch per call)" >> $OUT/c_client.txt; DETEXHIP_RESIDENT_US=0 tests/c_client/detex_client --latency >> $OUT/c_client.txt
+echo "-- the same program linked against the compiled reference (one host thread)" >> $OUT/c_client.txt; [ -x tests/c_client/detex_client_reflib ] && tests/c_client/detex_client_reflib --latency >> $OUT/c_client.txt
+echo "== host code under ASan/UBSan with the device"; ASAN_OPTIONS=detect_leaks=0 timeout 300 tests/host_san/api_san 2>&1 | tail -3 | tee $OUT/api_san_gpu.txt
 ldd tests/c_client/detex_client | grep -i "amdhip\|detexhip" >> $OUT/c_client.txt
 echo "== per-format table, all formats, streams U / M / C, linear and tiled"
 timeout 900 python bench.py --no-cpu --no-extras --formats-json $OUT/formats_8192.json > /dev/null 2> $OUT/formats.err; grep -c launch_us $OUT/formats.err
@@ -47,6 +50,6 @@ PY
 done | tee $OUT/sq_per_wave.txt
 echo "== small calls"; timeout 300 python tools/gpu_small_latency.py detex_amd/lib/libdetexhip.so 2>/dev/null | tee $OUT/small_latency.jsonl | cut -c1-200
 echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
-echo "== fuzz 45 s"; timeout 300 python tools/gpu_fuzz.py 45 20000 2>&1 | tail -1 | tee $OUT/fuzz.log
+echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 40000 2>&1 | tail -1 | tee $OUT/fuzz.log
 rm -rf $OUT/prof_trace $OUT/pmc_*_*_* 2>/dev/null
 echo "== done"
