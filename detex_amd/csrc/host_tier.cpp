@@ -308,15 +308,15 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
 	};
 	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
-		// the smallest linear textures, from the second call in a row on: a request to the resident kernel instead of a launch
-		if (!tiled && wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {
+		// the smallest textures (either layout), from the second call in a row on: a request to the resident kernel instead of a launch
+		if (wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {
 			const int epi = prepared_epilogue(texture->format, pixel_format);
 			if (epi == -2) return false;
 			if (c.service.wanted(f, epi)) {
 				// (up to one tile: the blocks travel as tagged chunks the kernel reads along with its polls -- path_types.h: kResidentTagged)
 				const bool tagged = wb * hb <= 256u;
 				const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(),
-					tagged ? kResidentTagged : kResidentTexture };
+					tagged ? kResidentTagged : kResidentTexture, tiled ? 1u : 0u };
 				bool failed = false;
 				const uint32_t number = c.service.begin(f, epi);
 				if (number != 0u) {

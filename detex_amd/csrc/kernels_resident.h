@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void decode_resident(const ResidentArgs a) {
 		uint32_t q[7];
 #pragma unroll
 		for (int k = 0; k < 7; k++) q[k] = s_req[k];
-		const uint32_t seq = s_req[12], what = s_req[13];
+		const uint32_t seq = s_req[12], what = s_req[13], s_tiled = s_req[7];
 		__syncthreads();			// thread 0 writes s_req again in the next round
 		if (what == 0u) { speculative -= speculative != 0u ? 1u : 0u; continue; }
 		if (what == 2u) break;
@@ -131,19 +131,32 @@ __global__ __launch_bounds__(256) void decode_resident(const ResidentArgs a) {
 			lv.blocks = a.blocks; lv.pixels = a.pixels; lv.pitch = (uint64_t)q[0] * ROW;	// ROW dwords per four pixels = bytes per pixel
 			lv.width = q[0]; lv.height = q[1]; lv.width_in_blocks = q[2]; lv.n_blocks = q[2] * q[3];
 			lv.fast = (q[0] & 3u) == 0u && (q[1] & 3u) == 0u && q[2] * 4u == q[0] && q[3] * 4u == q[1];
+			const bool block_major = s_tiled != 0u;		// detexDecompressTextureTiled: block i's sixteen pixels at pixels + i * 16 * pixel size
+			const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+			Word blk;
 			if (q[6] == kResidentTagged) {
 				// (only the leader gets here.)  The chunks this poll read are this request's if they carry its number; otherwise they are
 				// read now -- after the request was seen, so they are
 				const bool mine = threadIdx.x >= lv.n_blocks || (t0.z == seq && (Dec::kBlockBytes == 8 || t1.z == seq));
 				if (!__syncthreads_and(with_chunks && mine)) load_system_2x16(my_chunks, t0, t1);
-				Word blk;
 				if constexpr (sizeof(Word) == 16) blk = Word{ t0.x, t0.y, t1.x, t1.y };
 				else blk = Word{ t0.x, t0.y };
-				decode_level_tile_from<Dec, EPI>(lv, threadIdx.x, &a.mail->status, q[5], [&](uint32_t) { return blk; });
 			} else {
 				n_tiles = lv.n_blocks > 256u ? (lv.n_blocks + 255u) / 256u : 1u;
 				if (blockIdx.x >= n_tiles) continue;		// (workgroup-uniform) woken for a texture with fewer tiles than workgroups
-				decode_level_tile<Dec, EPI>(lv, blockIdx.x * 256u + threadIdx.x, &a.mail->status, q[5]);
+				blk = load_block<Dec>(lv.blocks, i < lv.n_blocks ? i : 0u);
+			}
+			if (block_major) {
+				if (i < lv.n_blocks) {
+					uint32_t o[4 * ROW];
+					const bool ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, q[5], o);
+					u32x4 *out = reinterpret_cast<u32x4 *>(a.pixels + (uint64_t)i * (16u * ROW));
+#pragma unroll
+					for (int k = 0; k < ROW; k++) out[k] = u32x4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+					raise_status(!ok, &a.mail->status);
+				}
+			} else {
+				decode_level_tile_from<Dec, EPI>(lv, i, &a.mail->status, q[5], [&](uint32_t) { return blk; });
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");	// system scope: this thread's stores are on their way to host memory

@@ -61,7 +61,7 @@ enum : uint32_t { kResidentRunning = 1, kResidentExiting = 2, kResidentExited = 
 // Pinned host memory, 64-byte lines with ONE writing side each.  A request is four 16-byte chunks {request number, three payload
 // words}, each written by the host with one 16-byte store and read by the kernel with one 16-byte load: a request is taken when all
 // four carry the same new number (no ordering between the four reads is assumed).  Payload words: 0-3 the block (kResidentBlock) or
-// width, height, width_in_blocks, height_in_blocks; 4 mode_mask; 5 flags; 6 kind; 7-11 unused.
+// width, height, width_in_blocks, height_in_blocks; 4 mode_mask; 5 flags; 6 kind; 7 block-major output (texture.c:77-98); 8-11 unused.
 // kResidentTagged = a texture of at most 256 blocks whose blocks the host has laid out as 16-byte chunks {eight block bytes, request
 // number, 0}, too (one chunk per 8-byte block, two per 16-byte block): the leading workgroup reads its lanes' chunks WITH every poll
 // of the request line, and a chunk that carries the request's number is that request's data whenever it was read -- so the second

@@ -37,8 +37,8 @@ DETEXHIP_API int detexhipGetDeviceCount(void);
 DETEXHIP_API int detexhipSetDevice(int device);
 DETEXHIP_API void detexhipReleaseThreadResources(void);
 DETEXHIP_API const char *detexhipVersion(void);
-/* The smallest host-pointer calls (one block: detexDecompressBlock*, detex.h:435-531 / texture.c:55-70; linear textures of up to
- * 1024 blocks: texture.c:105-145) cost a kernel launch and its completion each -- 7 us / 11 us on the test box against the
+/* The smallest host-pointer calls (one block: detexDecompressBlock*, detex.h:435-531 / texture.c:55-70; textures of up to
+ * 1024 blocks, linear or block-major: texture.c:77-145) cost a kernel launch and its completion each -- 7 us / 11 us on the test box against the
  * reference's 3 us / 9 us on one host thread.  From the SECOND such call in a row of one (texture format, pixel format) pair on, the
  * calling thread's requests go to a kernel that stays resident and polls a request line in pinned host memory (4-5 us / 7 us per
  * call), and that leaves by itself once no request has come for `microseconds` (default: DETEXHIP_RESIDENT_US or 250).  While it

@@ -100,6 +100,41 @@ def test_small_textures_with_target_formats(name, target, resident, oracle):
             assert ok == want_ok
 
 
+@pytest.mark.parametrize("name", ["BC1", "BC2", "RGTC1", "ETC2_EAC", "EAC_SIGNED_RG11", "BPTC", "BPTC_FLOAT"])
+def test_small_block_major_textures(name, resident, oracle):
+    """detexDecompressTextureTiled (texture.c:77-98) on 1 to 1024 blocks, three calls per size: one tile (tagged chunks) and several"""
+    lib = resident
+    fmt = F.BY_NAME[name]
+    served0, _ = _stats(lib.lib)
+    calls = 0
+    for (wb, hb) in [(1, 1), (16, 16), (5, 3), (32, 32), (64, 9), (16, 17)]:
+        for rep in range(3):
+            data = ol.stream_u(fmt, wb * hb, seed=0x71ED + 13 * rep + wb * 37 + hb)
+            ok, got = lib.tiled(fmt, data, wb, hb)
+            want_ok, want = oracle.tiled(fmt, data, wb, hb)
+            assert np.array_equal(got, want), (name, wb, hb, rep)
+            assert ok == want_ok
+            calls += 1
+    served1, _ = _stats(lib.lib)
+    assert served1 - served0 in (calls - 1, calls)
+
+
+def test_linear_and_block_major_requests_share_a_kernel(resident, oracle):
+    lib = resident
+    fmt = F.BY_NAME["BC3"]
+    _, started0 = _stats(lib.lib)
+    for k in range(8):
+        data = ol.stream_u(fmt, 256, seed=40 + k)
+        if k % 2:
+            ok, got = lib.tiled(fmt, data, 16, 16)
+            assert np.array_equal(got, oracle.tiled(fmt, data, 16, 16)[1])
+        else:
+            ok, got = lib.linear(fmt, data, 64, 64)
+            assert np.array_equal(got, oracle.linear(fmt, data, 64, 64)[1])
+    _, started1 = _stats(lib.lib)
+    assert started1 - started0 <= 1
+
+
 def test_format_switches_and_block_texture_mix(resident, oracle):
     """pairs alternate: a resident kernel of one pair must never answer a request meant for another (it is stopped first), and
     one-block and texture requests of one pair share a kernel"""
