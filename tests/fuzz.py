@@ -2,8 +2,9 @@
 tools/gpu_fuzz.py (open-ended sweep on the GPU box).  One seed = every format once: a random geometry (power-of-two and
 non-power-of-two block widths, both sides of the several-blocks-per-lane condition, clipped sizes, a padded pitch now and
 then), a stream biased towards repeated blocks one time in three, decoded linear (native target and, one time in three, a
-random epilogue target), block-major and through the per-block API with a random mode mask -- each against the CPU oracle,
-bit for bit.  Test infrastructure only."""
+random epilogue target), block-major and through the per-block API with a random mode mask -- and, for textures of up to 1024
+blocks, through the HOST-POINTER entry points twice in a row (the second call is answered by the resident kernel) plus two one-block
+leaf calls with a random mode mask -- each against the CPU oracle, bit for bit.  Test infrastructure only."""
 import numpy as np
 
 from detex_amd import formats as F
@@ -13,10 +14,20 @@ GEOMETRIES = [(256, 64), (1024, 128), (72, 40), (100, 36), (4, 4), (260, 12), (1
               (2004, 24), (4093, 9), (36, 256), (12, 1024), (8192, 8), (1, 1), (3, 7), (4100, 4)]
 
 
+_API = []
+
+
+def _host_api(binding):
+    if not _API:
+        _API.append(ol.DetexAPI(binding.LIB_PATH))
+    return _API[0]
+
+
 def run_seed(seed, oracle, binding, torch):
     """returns the number of decode calls checked"""
     rng = np.random.default_rng(seed)
     cases = 0
+    api = _host_api(binding)
     for fmt in F.FORMATS:
         W, H = GEOMETRIES[int(rng.integers(0, len(GEOMETRIES)))]
         wb, hb = (W + 3) // 4, (H + 3) // 4
@@ -64,4 +75,22 @@ def run_seed(seed, oracle, binding, torch):
         assert np.array_equal(got_ok.cpu().numpy()[:wb * hb].astype(bool), ok_b), ("blocks ok", hex(mask)) + where
         assert np.array_equal(got_b.cpu().numpy().reshape(-1)[:wb * hb * 16 * px], want_b.reshape(-1)), ("blocks", hex(mask)) + where
         cases += 2
+        # host-pointer tier, small textures: two calls in a row (launch, then the resident kernel), either layout; two leaf calls
+        if wb * hb <= 1024:
+            for rep in range(2):
+                if rng.integers(0, 3) == 0:
+                    ok_h, got_h = api.tiled(fmt, data, wb, hb)
+                    assert np.array_equal(got_h, want_t), ("host tiled", rep) + where
+                else:
+                    ok_h, got_h = api.linear(fmt, data, W, H)
+                    assert np.array_equal(got_h, np.asarray(want).reshape(-1)), ("host linear", rep) + where
+                assert ok_h == ok_o, ("host ok", rep) + where
+            blk = data.reshape(-1, fmt.block_bytes)
+            for rep in range(2):
+                k = int(rng.integers(0, len(blk)))
+                ok_1, got_1 = api.block(fmt, blk[k], mode_mask=mask)
+                assert ok_1 == bool(ok_b[k]), ("host block ok", hex(mask)) + where
+                if ok_1:
+                    assert np.array_equal(got_1, want_b[k]), ("host block", hex(mask)) + where
+            cases += 4
     return cases
