@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <chrono>
+#include <cstring>
+#include <cstdlib>
 #define REP16(x) x x x x x x x x x x x x x x x x
 #define KERNEL(NAME, ASM)                                                                     \
 	__global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, uint32_t seed, int iters) {  \
@@ -103,9 +106,45 @@ KERNEL(dpp_mov, "v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask
 KERNEL(lshl_inline, "v_lshlrev_b32 %0, 2, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 2, %2\n v_lshlrev_b32 %3, 3, %3")
 KERNEL(add_self, "v_add_u32 %0, %0, %0\n v_add_u32 %1, %1, %1\n v_add_u32 %2, %2, %2\n v_add_u32 %3, %3, %3")
 
+// a 16-byte LDS read per instruction at a computed (conflict-free) address, four independent chains (what the BPTC decoders' subset rows cost)
+__global__ __launch_bounds__(256) void k_ds_read_b128(uint32_t *out, uint32_t seed, int iters) {
+	__shared__ uint4 rows[4 * 256];
+	for (int k = threadIdx.x; k < 4 * 256; k += 256) rows[k] = uint4{ seed + k, seed ^ k, seed * k, seed - k };
+	__syncthreads();
+	uint32_t a = threadIdx.x, acc = 0;
+	for (int i = 0; i < iters; i++) {
+#pragma unroll
+		for (int r = 0; r < 64; r++) {
+			const uint4 v = rows[((a + r) & 3u) * 256u + threadIdx.x];
+			acc += v.x ^ v.w;
+			a += v.y & 1u;
+		}
+	}
+	out[blockIdx.x * 256 + threadIdx.x] = acc ^ a;
+}
+
+// LDS instructions with next to no VALU around them: sixteen reads (or writes) at immediate offsets from one per-lane base, one xor each
+#define LDS_KERNEL(NAME, ASM, STRIDE)                                                                                   \
+	__global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, uint32_t seed, int iters) {                          \
+		__shared__ uint4 rows[16 * 256];                                                                                 \
+		for (int k = threadIdx.x; k < 16 * 256; k += 256) rows[k] = uint4{ seed + k, seed ^ k, seed * k, seed - k };      \
+		__syncthreads();                                                                                                 \
+		const uint32_t base = (uint32_t)(uintptr_t)rows + threadIdx.x * STRIDE;                                          \
+		u4 acc = { seed, 1, 2, 3 };                                                                                      \
+		for (int i = 0; i < iters; i++) {                                                                                \
+			REP16(asm volatile(ASM : "+v"(acc) : "v"(base) : "memory");)                                                  \
+		}                                                                                                                \
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+		out[blockIdx.x * 256 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;                                             \
+	}
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+LDS_KERNEL(lds_read_b128, "ds_read_b128 %0, %1 offset:4096\n s_waitcnt lgkmcnt(0)", 16)
+LDS_KERNEL(lds_read_b128_x4, "ds_read_b128 %0, %1 offset:4096\n ds_read_b128 %0, %1 offset:8192\n ds_read_b128 %0, %1 offset:12288\n ds_read_b128 %0, %1 offset:16384\n s_waitcnt lgkmcnt(0)", 16)
+LDS_KERNEL(lds_write_b128_x4, "ds_write_b128 %1, %0 offset:4096\n ds_write_b128 %1, %0 offset:8192\n ds_write_b128 %1, %0 offset:12288\n ds_write_b128 %1, %0 offset:16384\n s_waitcnt lgkmcnt(0)", 16)
+
 struct Entry { const char *name; void (*fn)(uint32_t *, uint32_t, int); };
 #define E(NAME) { #NAME, k_##NAME }
-int main() {
+int main(int argc, char **argv) {
 	Entry table[] = { E(v_add_u32), E(v_mul_u32_u24), E(v_mul_i32_i24), E(v_mad_i32_i24), E(v_mad_u32_u24), E(v_mul_lo_u32), E(v_mul_hi_u32),
 		E(v_bfe_u32), E(v_bfi_b32), E(v_perm_b32), E(v_alignbit_b32), E(v_lshl_or_b32), E(v_and_or_b32), E(v_med3_i32), E(v_lshrrev_b32),
 		E(v_pk_mad_u16), E(v_cndmask_b32), E(v_cmp_cnd), E(v_bfrev_b32), E(cnd_sgpr_mask), E(cnd_add_1to1), E(cnd_bfe_1to1), E(cnd_1_in_4), E(cmp_then_3cnd), E(cnd_e64_vcc), E(bfe_i32_mask), E(dep1_add), E(dep2_add), E(dep1_bfe), E(dep2_bfe), E(dep1_mix), E(dep2_mix),
@@ -113,12 +152,31 @@ int main() {
 		E(v_pk_ashr), E(v_lshl_add), E(v_add3), E(v_xor), E(v_sub), E(v_lshlrev), E(v_min_max), E(v_ffbl), E(mix_add_bfe), E(mix_valu_salu), E(mix_add_salu),
 		E(lshl_vgpr), E(lshr_inline), E(ashr_inline), E(v_or), E(v_not), E(v_bitop3), E(v_bcnt), E(and_sdwa), E(add_sdwa), E(mov_sdwa), E(add_lit), E(max_u32),
 		E(cmp_only), E(pk_mul_lo), E(pk_min_max),
-		E(bitop3_sgpr), E(bitop3_inline), E(add_sgpr), E(xor_sgpr), E(lshr_sgpr_amt), E(lshr_sgpr_val), E(mov_sgpr), E(sub_sgpr), E(and_vcc_lo), E(dpp_mov), E(lshl_inline), E(add_self) };
+		E(bitop3_sgpr), E(bitop3_inline), E(add_sgpr), E(xor_sgpr), E(lshr_sgpr_amt), E(lshr_sgpr_val), E(mov_sgpr), E(sub_sgpr), E(and_vcc_lo), E(dpp_mov), E(lshl_inline), E(add_self), E(ds_read_b128), E(lds_read_b128), E(lds_read_b128_x4), E(lds_write_b128_x4) };
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount, blocks = cus * 8, iters = 512;	// 8 blocks x 4 waves = 32 waves/CU = 8 per SIMD
 	const double clk = prop.clockRate * 1e3;
 	uint32_t *out; hipMalloc(&out, blocks * 256 * 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	if (argc >= 4 && !strcmp(argv[1], "loop")) {
+		// valu_rates loop NAME SECONDS: the one kernel back to back for that long (tools/gpu_power_classes.py samples clock and power meanwhile)
+		for (const Entry &t : table) {
+			if (strcmp(t.name, argv[2])) continue;
+			const double seconds = atof(argv[3]);
+			const auto t0 = std::chrono::steady_clock::now();
+			long launches = 0;
+			while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+				for (int k = 0; k < 8; k++) hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(256), 0, 0, out, 12345u, 4096);
+				hipDeviceSynchronize();
+				launches += 8;
+			}
+			const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			printf("loop %s launches %ld seconds %.3f wave_instructions_per_s %.4g\n", t.name, launches, elapsed, (double)launches * blocks * 4 * 4096.0 * 64 / elapsed);
+			return 0;
+		}
+		printf("loop: no kernel named %s\n", argv[2]);
+		return 1;
+	}
 	printf("%d CUs, %.0f MHz nominal; cycles per wave64 instruction per SIMD (8 waves/SIMD):\n", cus, clk / 1e6);
 	for (const Entry &t : table) {
 		hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(256), 0, 0, out, 12345u, 8);
