@@ -129,7 +129,7 @@ private:
 	void post(const uint32_t payload[12], uint32_t number);
 	bool stop();
 };
-int resident_idle_microseconds();	// detexhipSetResidentIdleMicroseconds, else DETEXHIP_RESIDENT_US, else 250; 0 = no resident kernels
+int resident_idle_microseconds();	// detexhipSetResidentIdleMicroseconds, else DETEXHIP_RESIDENT_US, else 100; 0 = no resident kernels
 
 // ---- host tier <-> multi-device (host_tier.cpp, multi_device.cpp) --------------------------------------------------------------------
 void release_thread_context();

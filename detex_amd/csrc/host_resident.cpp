@@ -31,7 +31,7 @@ int resident_idle_microseconds() {
 	int v = g_idle_us.load(std::memory_order_relaxed);
 	if (v < 0) {
 		const char *env = getenv("DETEXHIP_RESIDENT_US");
-		v = env ? atoi(env) : 250;
+		v = env ? atoi(env) : 100;		// (also what an application's hipDeviceSynchronize() can wait longer right after a small call)
 		if (v < 0) v = 0;
 		if (v > 1000000) v = 1000000;
 		g_idle_us.store(v, std::memory_order_relaxed);

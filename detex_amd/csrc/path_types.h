@@ -52,7 +52,7 @@ struct Completion { uint32_t *done; uint32_t *counter; uint32_t ticket; };
 // launch per call: profiles/r04/host_tier_latency.txt); a workgroup that is ALREADY RUNNING and polls a request line in pinned host
 // memory answers in 4.2 / 6.4 us (tools/ubench/host_latency.hip: `resident`).  So the second small call in a row of one (format,
 // target) pair starts such a kernel, later ones are posted to it, and it leaves by itself once no request has come for the idle time
-// (detexhipSetResidentIdleMicroseconds; a few hundred microseconds), after announcing that in `state`.
+// (detexhipSetResidentIdleMicroseconds; 100 us by default), after announcing that in `state`.
 constexpr uint32_t kResidentWorkgroups = 4;					// textures of up to 4 x 256 blocks (128 x 128 pixels)
 constexpr uint32_t kResidentMaxBlocks = 256u * kResidentWorkgroups;
 constexpr uint32_t kResidentBlockBytes = kResidentMaxBlocks * 16u, kResidentPixelBytes = kResidentMaxBlocks * 16u * 8u;

@@ -41,7 +41,7 @@ DETEXHIP_API const char *detexhipVersion(void);
  * 1024 blocks, linear or block-major: texture.c:77-145) cost a kernel launch and its completion each -- 7 us / 11 us on the test box against the
  * reference's 3 us / 9 us on one host thread.  From the SECOND such call in a row of one (texture format, pixel format) pair on, the
  * calling thread's requests go to a kernel that stays resident and polls a request line in pinned host memory (4-5 us / 7 us per
- * call), and that leaves by itself once no request has come for `microseconds` (default: DETEXHIP_RESIDENT_US or 250).  While it
+ * call), and that leaves by itself once no request has come for `microseconds` (default: DETEXHIP_RESIDENT_US or 100).  While it
  * lingers a hipDeviceSynchronize() of the application waits that much longer.  0 = never leave a kernel behind (a launch per call).
  * Process-wide; applies to kernels started afterwards.  Returns the previous value. */
 DETEXHIP_API int detexhipSetResidentIdleMicroseconds(int microseconds);

@@ -86,7 +86,7 @@ def test_c_client_decodes_the_fixtures_and_a_full_size_stream(built, golden_json
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("idle_us", ["250", "0", "3", "1"])
+@pytest.mark.parametrize("idle_us", ["100", "0", "3", "1"])
 def test_c_client_back_to_back_small_calls(built, idle_us):
     """2200 one-block calls and 2200 small textures per size in a tight loop from compiled C, another block every call: with the
     resident kernel answering (default idle time), with a launch per call (0), and with an idle time so short that the kernel keeps
