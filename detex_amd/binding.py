@@ -44,6 +44,10 @@ def load():
     lib.detexhipKernelName.argtypes = [ctypes.c_uint32]
     lib.detexhipSetDevice.argtypes = [ctypes.c_int]
     lib.detexhipSetKernelVariant.argtypes = [ctypes.c_int]
+    lib.detexhipSetResidentIdleMicroseconds.argtypes = [ctypes.c_int]
+    lib.detexhipSetResidentIdleMicroseconds.restype = ctypes.c_int
+    lib.detexhipGetResidentStats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+    lib.detexhipGetResidentStats.restype = None
     lib.detexhipDecompressTextureLinearDevice.argtypes = [
         ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t,
         ctypes.c_uint32, _vp, _vp]
@@ -67,6 +71,18 @@ def _check(rc, what):
 
 def set_kernel_variant(v):
     load().detexhipSetKernelVariant(int(v))
+
+
+def set_resident_idle_us(us):
+    """idle time of the host tier's resident service kernel (0 = a launch per small call); returns the previous value"""
+    return load().detexhipSetResidentIdleMicroseconds(int(us))
+
+
+def resident_stats():
+    """(requests answered by resident kernels, resident kernels started) of the calling thread"""
+    a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    load().detexhipGetResidentStats(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def kernel_name(fmt):
