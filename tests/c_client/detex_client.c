@@ -9,7 +9,7 @@
  *                                                        FORMAT (detex.h:613-727), decoded and digested the same way
  *   detex_client --sha256-selftest       digest of "abc" and of 1,000,000 'a' (FIPS 180-4 vectors)
  *   detex_client --latency               microseconds per call (median of 2000) of detexDecompressBlockBC1 and of
- *                                        detexDecompressTextureLinear on 64x64 / 256x256 BC1 textures: what a C caller pays, without
+ *                                        detexDecompressTextureLinear on 64x64 ... 1024x1024 BC1 textures: what a C caller pays, without
  *                                        the ctypes overhead bench.py's host_tier_small carries
  */
 #define _POSIX_C_SOURCE 200809L
@@ -110,13 +110,14 @@ static int latency(void) {
 	}
 	qsort(t, N, sizeof t[0], cmp_double);
 	printf("latency one_block_us=%.2f p90=%.2f\n", t[N / 2], t[N * 9 / 10]);
-	for (int side = 64; side <= 256; side *= 2) {
+	for (int side = 64; side <= 1024; side *= 2) {
+		const int n = side <= 256 ? N : 300;			/* (the large ones take 0.1-1.5 ms per call on the CPU) */
 		const size_t nb = (size_t)(side / 4) * (side / 4), out_bytes = (size_t)side * side * 4;
 		uint8_t *blocks = (uint8_t *)malloc(nb * 8), *pixels = (uint8_t *)malloc(out_bytes), *expect = (uint8_t *)malloc(out_bytes);
 		for (size_t k = 0; k < nb * 8; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
 		detexTexture tex;
 		tex.format = DETEX_TEXTURE_FORMAT_BC1; tex.data = blocks; tex.width = side; tex.height = side; tex.width_in_blocks = side / 4; tex.height_in_blocks = side / 4;
-		for (int i = -WARM; i < N; i++) {
+		for (int i = -WARM; i < n; i++) {
 			blocks[4] = (uint8_t)i;
 			const double t0 = now_us();
 			if (!detexDecompressTextureLinear(&tex, pixels, DETEX_PIXEL_FORMAT_RGBA8)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
@@ -125,8 +126,8 @@ static int latency(void) {
 			else if (((i + WARM) & 255) == 0 && memcmp(expect, pixels, out_bytes) != 0) wrong++;
 			else if (((i + WARM) & 255) == 1 && memcmp(expect, pixels, 64) == 0) wrong++;
 		}
-		qsort(t, N, sizeof t[0], cmp_double);
-		printf("latency %dx%d_us=%.2f p90=%.2f\n", side, side, t[N / 2], t[N * 9 / 10]);
+		qsort(t, n, sizeof t[0], cmp_double);
+		printf("latency %dx%d_us=%.2f p90=%.2f\n", side, side, t[n / 2], t[n * 9 / 10]);
 		free(blocks); free(pixels); free(expect);
 	}
 	printf("latency wrong_results=%d\n", wrong);
