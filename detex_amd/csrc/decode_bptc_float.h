@@ -393,11 +393,10 @@ DH int32_t bc6h_unquantize_signed_x4(int32_t x, const Bc6hSignedUnq &k) {
 // sign_bits = 0x80008000 in a VGPR (Bc6hLane::bit12 explains why)
 DH uint32_t bc6h_sign_magnitude_pk(uint32_t p, uint32_t sign_bits) {
 	const uint32_t a = pk_max16(p, pk_sub16(0u, p));				// |v| (0x8000 stays 0x8000: read as unsigned below)
-	// From here on plain 32-bit operations do the work of packed ones at nearly twice the issue rate (adds, logic ops and right
-	// shifts: ~2.5 cycles against ~4.4 for v_pk_*; tools/isa_mix.py): with |v| <= 0x8000 per lane no add below carries, and no
-	// subtraction borrows, across the lane boundary, and the mask keeps the upper lane's bits out of the lower lane's shift.
-	const uint32_t t = ((a + 0x001F001Fu) & 0xFFE0FFE0u) >> 5;			// ceil(|v| / 32) per lane
-	const uint32_t m = a - t;							// |v| - ceil(|v| / 32) <= 0x7C00
+	// (Packed operations here: one instruction less than the plain 32-bit form with its lane mask.  This kernel runs at the board's
+	// power cap, where an instruction costs about the same energy whatever its issue class -- profiles/AB_RECORD.md -- so the count
+	// is what matters.  The last two steps stay plain: with m <= 0x7C00 per lane nothing carries across the lane boundary.)
+	const uint32_t m = pk_sub_u16(a, pk_lshr16(pk_add16(a, 0x001F001Fu), 5));	// |v| - ceil(|v| / 32) <= 0x7C00
 	return m | and3(m + 0x7FFF7FFFu, p, sign_bits);
 }
 
