@@ -8,7 +8,7 @@ ARCH  ?= gfx950
 CSRC  := detex_amd/csrc
 LIB   := detex_amd/lib/libdetexhip.so
 LIB_AB := build/explib/libdetexhip_ab.so
-HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/ab/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
+HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
 
 all: lib oracle ubench c-client
 lib: $(LIB)
@@ -36,13 +36,19 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+# (measurement build only: the translation units of tools/ab include the product's headers and format tables, never the other way round)
+$(OBJDIR)/%_ab.o: tools/ab/%_ab.hip $(HDRS) $(wildcard tools/ab/*.h) $(wildcard $(CSRC)/formats_*.hip)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -c -o $@ $<
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-# measurement build with the rejected A/B kernels (profiles/AB_RECORD.md; DETEXHIP_LIB=$(LIB_AB) bench.py --variant N)
+# measurement build with the rejected A/B kernels (profiles/AB_RECORD.md; DETEXHIP_LIB=$(LIB_AB) bench.py --variant N): the product's
+# host objects and histogram kernels + tools/ab's format-table translation units in place of the product's
+SRCS_HIP_AB := formats_s3tc_rgtc_ab formats_etc_eac_ab formats_bptc_ab formats_bptc_float_ab histogram
 lib-ab:
-	$(MAKE) lib LIB=$(LIB_AB) OBJDIR=build/obj_ab EXTRA_HIPFLAGS=-DDETEXHIP_AB_VARIANTS
+	$(MAKE) lib LIB=$(LIB_AB) OBJDIR=build/obj_ab SRCS_HIP="$(SRCS_HIP_AB)"
 
 # the library's host code under AddressSanitizer + UndefinedBehaviorSanitizer with a main that calls every entry point with hostile
 # arguments (tests/test_sanitized_host.py); host code only is instrumented (-fno-gpu-sanitize)

@@ -528,7 +528,7 @@ template <bool UNIFORM> struct DecBPTCT {
 	// One workgroup per tile, like every other decoder.  A persistent grid (workgroups looping over tiles, the tables copied
 	// once per resident workgroup, the next tile's block prefetched) was the better choice while the tables were 7.5 KiB
 	// (58.8 vs 62.0 us, stream U); with today's 3.6 KiB it is the worse one -- same run, 8192^2, streams U / C: persistent
-	// 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (ab/kernels_persistent.h keeps that kernel for the
+	// 57.4-57.9 / 50.7-50.8 us, one tile per workgroup 55.0 / 48.8 (tools/ab/kernels_persistent.h keeps that kernel for the
 	// measurement build).  The block-major kernel likewise (U / M / C: 62.5-63.3 / 63.8-64.7 / 52.0 vs 64.5 / 66.1 / 47.4).
 	static DH void prepare() { bc7_prepare(); }
 	// the block-major exchange (kernels.h: decode_blocks) stages inside this decoder's own, by then dead, lane rows

@@ -67,22 +67,15 @@ bool stream_on_current_device(hipStream_t stream, const char *who) {
 static thread_local ThreadSettings t_settings;
 ThreadSettings &thread_settings() { return t_settings; }
 
-int max_variant() {
-#ifdef DETEXHIP_AB_VARIANTS
-	return 7;			// ab/ab_dispatch.h
-#else
-	return 0;
-#endif
-}
+// The product library has ONE kernel per format and layout (variant 0).  A measurement build (tools/ab: its own translation units, which
+// include this library's headers and replace the format tables' launchers) raises the limit from a static initialiser.
+int g_max_variant = 0;
+int max_variant() { return g_max_variant; }
 int current_variant() {
 	ThreadSettings &s = t_settings;
 	if (s.variant < 0) {
-#ifdef DETEXHIP_AB_VARIANTS
-		const char *env = getenv("DETEXHIP_VARIANT");	// measurement build only
+		const char *env = getenv("DETEXHIP_VARIANT");	// (always 0 in the product library: the limit above)
 		s.variant = env ? atoi(env) : 0;
-#else
-		s.variant = 0;
-#endif
 		if (s.variant < 0 || s.variant > max_variant()) s.variant = 0;
 	}
 	return s.variant;

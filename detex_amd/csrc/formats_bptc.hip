@@ -2,20 +2,12 @@
 // texture.c:27-48.
 #include "decode_bptc.h"
 #include "launchers.h"
-#ifdef DETEXHIP_AB_VARIANTS
-#include "ab/decode_bptc_r01.h"		// variants 3 / 4: the round-1 decoders
-#include "ab/kernels_sorted.h"		// variant 5: mode-sorted waves
-#endif
 
 namespace detexhip {
 
 // the kernels off the throughput path (clipped geometry, mip levels, the checked per-block batch) take the decoder without its
 // wave-uniform per-record copies
 template <> struct PlainDecoder<DecBPTCT<true>> { using type = DecBPTCPlain; };
-#ifdef DETEXHIP_AB_VARIANTS
-template <> struct AltDecoder<DecBPTC> { using type = r01::DecBPTCRegisterSelect; };
-template <> struct AltDecoder2<DecBPTC> { using type = r01::DecBPTCLdsFields; };
-#endif
 
 const FormatEntry *formats_bptc() {
 	static const FormatEntry rows[1] = { FMT(BPTC, DecBPTC, kClassBPTC, 0, 0) };

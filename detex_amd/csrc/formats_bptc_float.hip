@@ -9,10 +9,6 @@
 
 namespace detexhip {
 
-#ifdef DETEXHIP_AB_VARIANTS
-template <bool S> struct AltDecoder<DecBPTCFloatT<S, false>> { using type = DecBPTCFloatT<S, true>; };	// variant 3: field scatter as a per-mode switch
-#endif
-
 // (resident workgroups per CU: BC6H gains 11 % on coherent content at five -- its fixture tiled, which is what encoder-made textures
 // look like -- at the price of 2.6 % on uniform-random blocks, where the kernel sits at the board's power cap and needs every wave;
 // signed BC6H has no fixture to show a gain and keeps all of them.  Block-major: four.)

@@ -2,9 +2,6 @@
 // (decompress-rgtc.c): format indices 1-8 of the table the reference keeps in texture.c:27-48.
 #include "decode_s3tc_rgtc.h"
 #include "launchers.h"
-#ifdef DETEXHIP_AB_VARIANTS
-#include "ab/variant_tile4x4.h"		// variant 1: BC1 in 4x4-block wave tiles
-#endif
 
 namespace detexhip {
 

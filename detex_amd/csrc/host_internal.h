@@ -88,6 +88,7 @@ ThreadSettings &thread_settings();
 int current_variant();
 uint32_t current_spec_flags();						// the decoders' kFlagSpec... bits for the calling thread's quirk mask
 int max_variant();							// 0 in the product library
+extern int g_max_variant;					// (raised by the measurement build of tools/ab)
 
 // detexhipDecompressTextureLinearDevice with the quirk flags and kernel variant given explicitly instead of read from the calling
 // thread's settings: for worker threads that decode on behalf of a caller (multi_device.cpp)

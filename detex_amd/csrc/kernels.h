@@ -395,7 +395,7 @@ DH bool stores_enabled(const uint32_t *o) {
 // ---- linear layout, fast path: width % 4 == 0, vector-aligned rows ----------------------------
 // One workgroup per tile of 256 consecutive blocks, dispatched by the hardware.  (A persistent grid -- workgroups looping
 // over tiles, tables copied once per resident workgroup, next tile's block prefetched -- measured 1-20 % slower for every
-// format, BC7 included once its tables had shrunk: profiles/AB_RECORD.md; that kernel lives in ab/kernels_persistent.h.)
+// format, BC7 included once its tables had shrunk: profiles/AB_RECORD.md; that kernel lives in tools/ab/kernels_persistent.h.)
 template <class Dec, int EPI, bool NT>
 __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(const void *__restrict__ blocks,
 		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,

@@ -38,13 +38,6 @@ template <class Dec, class F> hipError_t with_epilogue(int epi, F &&fn) {
 // are not on the throughput path (clipped geometry, mip levels), to bound code size (specialised in formats_bptc.hip)
 template <class Dec> struct PlainDecoder { using type = Dec; };
 
-#ifdef DETEXHIP_AB_VARIANTS
-}  // namespace detexhip
-// rejected A/B kernels (profiles/AB_RECORD.md): only in the measurement build (make lib-ab), never in the product library
-#include "ab/ab_dispatch.h"
-namespace detexhip {
-#endif
-
 // decode_linear's geometry: whole blocks, vector-aligned rows.  `sector_aligned`: every wave's 1 KiB store run also starts on
 // a 64-byte boundary (row bytes, pitch and base multiples of 64) -- where it does not, the staged kernel is the faster one.
 template <class Dec, int EPI> bool fast_geometry(const Geometry &g, bool *sector_aligned) {
@@ -110,10 +103,6 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 	// power-of-two width keeps those on sector boundaries anyway)
 	constexpr bool kStagedWhenUnaligned = EpilogueOf<Dec, EPI>::kRowDwords >= 3;
 	if (fast_geometry<Dec, EPI>(g, &sector_aligned) && (sector_aligned || !kStagedWhenUnaligned)) {
-#ifdef DETEXHIP_AB_VARIANTS
-		hipError_t ab_result;
-		if (g.variant != 0 && ab_launch_linear<Dec, EPI>(g, &ab_result)) return ab_result;
-#endif
 		// narrow pixels (RGTC1, SIGNED_RGTC1): several blocks per lane, so that a store instruction covers a longer run
 		constexpr int kRow = EpilogueOf<Dec, EPI>::kRowDwords, kGroup = kRow * LaneBlocks<Dec>::value <= 4 ? LaneBlocks<Dec>::value : 1;
 		if constexpr (kGroup > 1) {

@@ -203,8 +203,8 @@ DETEXHIP_API void detexhipSetQuirks(uint32_t quirks);
 DETEXHIP_API uint32_t detexhipGetQuirks(void);
 
 /* Kernel-variant selection for A/B measurements (profiles/AB_RECORD.md).  The product library has ONE kernel per
- * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab,
- * -DDETEXHIP_AB_VARIANTS; detex_amd/csrc/ab/ab_dispatch.h lists them).  Unknown values fall back to 0.
+ * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab:
+ * the translation units of tools/ab, which include this library's sources; tools/ab/ab_dispatch.h lists them).  Unknown values fall back to 0.
  * Per calling thread.  Also settable with DETEXHIP_VARIANT. */
 DETEXHIP_API void detexhipSetKernelVariant(int variant);
 DETEXHIP_API int detexhipGetKernelVariant(void);

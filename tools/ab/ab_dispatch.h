@@ -1,5 +1,5 @@
 // ab/ab_dispatch.h -- launch-side selection of the rejected A/B kernels (profiles/AB_RECORD.md).
-// Only compiled with -DDETEXHIP_AB_VARIANTS (make lib-ab); the product library contains none of this.
+// Only compiled into the measurement build (make lib-ab: tools/ab/formats_*_ab.hip); the product library contains none of this.
 //   1  4x4-block wave tiles staged through LDS, lane = (block, texel row)           [BC1 only]
 //   2  default mapping with ordinary (cached) row stores
 //   3  BPTC_FLOAT field scatter as a per-mode switch; BPTC round-1 decoder with register-select texel stage
@@ -7,9 +7,12 @@
 //   5  BPTC with mode-sorted waves (workgroup counting sort by mode)
 //   6  persistent grid, twice as many workgroups as are resident at once (kernels_persistent.h)      [32-bit pixels]
 //   7  persistent grid, exactly the resident count
-// Included by launchers.h (after Geometry / PlainDecoder); the per-decoder hooks are ab_traits.h's templates, specialised by the
-// formats_*.hip translation unit that owns the decoder.
+// Included by the tools/ab/formats_*_ab.hip translation units AFTER the product's launchers.h; the per-decoder hooks are ab_traits.h's
+// templates, specialised by the translation unit that owns the decoder.  The product sources know nothing of this directory: an A/B
+// translation unit includes the product headers, re-points FMT()'s linear launcher at ab_linear<> below and then includes the product's
+// formats_*.hip for its table rows.
 #pragma once
+#include "launchers.h"
 #include "ab_traits.h"
 #include "kernels_persistent.h"
 
@@ -72,4 +75,27 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 	return false;
 }
 
+// the format table's linear launcher in the measurement build: variant 0, geometries the variants do not cover and variants a decoder
+// does not have go to the product's launcher
+template <class Dec> hipError_t ab_linear(const Geometry &g) {
+	if (g.variant != 0 && g.wb * g.hb != 0) {
+		hipError_t result = hipSuccess;
+		bool launched = false;
+		(void)with_epilogue<Dec>(g.epi, [&](auto epi) {
+			constexpr int EPI = decltype(epi)::value;
+			bool sector_aligned = false;
+			constexpr bool kStagedWhenUnaligned = EpilogueOf<Dec, EPI>::kRowDwords >= 3;
+			if (fast_geometry<Dec, EPI>(g, &sector_aligned) && (sector_aligned || !kStagedWhenUnaligned)) launched = ab_launch_linear<Dec, EPI>(g, &result);
+			return hipSuccess;
+		});
+		if (launched) return result;
+	}
+	return launch_linear<Dec>(g);
+}
+static const int g_raise_variant_limit = (g_max_variant = 7);
+
 }  // namespace detexhip
+
+#undef FMT
+#define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &ab_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
+	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS }

@@ -1,7 +1,7 @@
-// ab/ab_traits.h -- primary templates of the rejected A/B kernels' per-decoder hooks (profiles/AB_RECORD.md).  Only compiled with
-// -DDETEXHIP_AB_VARIANTS (make lib-ab); the product library contains none of this.  The formats_*.hip translation unit that owns
+// ab/ab_traits.h -- primary templates of the rejected A/B kernels' per-decoder hooks (profiles/AB_RECORD.md).  Only compiled into the
+// measurement build (make lib-ab); the product library contains none of this.  The tools/ab/formats_*_ab.hip translation unit that owns
 // a decoder specialises the hooks that exist for it (variant_tile4x4.h: BC1; kernels_sorted.h, decode_bptc_r01.h: BC7; BC6H's
-// switch-scatter decoder in formats_bptc_float.hip) AFTER including launchers.h and before its FMT() rows.
+// switch-scatter decoder in formats_bptc_float_ab.hip) AFTER including ab_dispatch.h and before the product's FMT() rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,5 +1,5 @@
 // ab/decode_bptc_r01.h -- the ROUND-1 BC7 decoders, kept only for A/B measurements against decode_bptc.h
-// (built with -DDETEXHIP_AB_VARIANTS; never part of the product library).  Original header follows.
+// (measurement build only, make lib-ab; never part of the product library).  Original header follows.
 //
 // BPTC (BC7), all eight modes, one lane per block, gfx950.
 //
@@ -19,9 +19,9 @@
 //
 // Reference quirk reproduced: in mode 6 the second P-bit (block bit 64) reads 0.
 #pragma once
-#include "../dev_common.h"
-#include "../decode_s3tc_rgtc.h"
-#include "../bptc_tables.inc"
+#include "dev_common.h"
+#include "decode_s3tc_rgtc.h"
+#include "bptc_tables.inc"
 
 namespace detexhip {
 namespace r01 {

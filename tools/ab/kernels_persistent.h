@@ -2,9 +2,9 @@
 // blockIdx.x, blockIdx.x + gridDim.x, ... on a grid that just fills the chip, the format tables are copied once per
 // resident workgroup and the next tile's block is requested before the current one is decoded.  Measured 1-20 % slower than
 // one workgroup per tile for every format (BC7: 58.3 vs 54.3 us once its tables had shrunk to 3.6 KiB), so the product
-// library does not contain it; only compiled with -DDETEXHIP_AB_VARIANTS (variants 6 / 7 of ab_dispatch.h).
+// library does not contain it; only compiled into the measurement build, make lib-ab (variants 6 / 7 of ab_dispatch.h).
 #pragma once
-#include "../kernels.h"
+#include "kernels.h"
 
 namespace detexhip {
 

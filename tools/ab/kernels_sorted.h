@@ -18,8 +18,8 @@
 // extra workgroup barriers and 32 KiB of LDS per workgroup (5 workgroups per CU) leave the SIMDs with too
 // few issuing waves.  A larger sort domain (1024 blocks) was costed at < 10 % fewer instructions.
 #pragma once
-#include "../kernels.h"
-#include "../decode_bptc.h"
+#include "kernels.h"
+#include "decode_bptc.h"
 #include "decode_bptc_r01.h"
 #include "ab_traits.h"
 

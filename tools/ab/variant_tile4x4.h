@@ -10,8 +10,8 @@
 // global_store_dwordx4.  Per store instruction the wave writes 16 image rows x 64 contiguous
 // bytes (half a 128 B line each), versus 1 KiB contiguous per store in the default mapping.
 #pragma once
-#include "../dev_common.h"
-#include "../decode_s3tc_rgtc.h"
+#include "dev_common.h"
+#include "decode_s3tc_rgtc.h"
 #include "ab_traits.h"
 
 namespace detexhip {

@@ -2,7 +2,7 @@
 # Measurement builds of libdetexhip into build/explib/ (never shipped with the product; the package directory holds the product library only):  bash tools/build_exp_libs.sh nostore nocompute prio1 ab_prio1 ...
 # Each name maps to overrides of detex_amd/csrc/tune.h's ProductTune; a generated header carries them and is named in
 # -DDETEXHIP_TUNE_HEADER (the one preprocessor switch of the measurement builds).  Names starting with ab_ also get
-# -DDETEXHIP_AB_VARIANTS (the rejected A/B kernels, bench.py --variant N / DETEXHIP_VARIANT=N), so knobs and variants combine.
+# the format-table translation units of tools/ab (the rejected A/B kernels, bench.py --variant N / DETEXHIP_VARIANT=N), so knobs and variants combine.
 #   nostore / nocompute     decode without its stores / stores without the decode
 #   wavesN                  BC7 register budget (waves per SIMD)
 #   plain                   BC7 without the wave-uniform per-record copies
@@ -26,9 +26,9 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/tune build/explib
 for v in "$@"; do
-  body=""; extra=""
+  body=""; srcs=""
   name=$v
-  case $v in ab_*) extra=-DDETEXHIP_AB_VARIANTS; v=${v#ab_} ;; esac
+  case $v in ab_*) srcs="formats_s3tc_rgtc_ab formats_etc_eac_ab formats_bptc_ab formats_bptc_float_ab histogram"; v=${v#ab_} ;; esac
   IFS='+' read -ra parts <<< "$v"
   for k in "${parts[@]}"; do
     case $k in
@@ -60,7 +60,7 @@ for v in "$@"; do
   hdr=$PWD/build/tune/tune_$name.h
   echo "struct Tune : ProductTune { $body};" > "$hdr"
   # (one sub-make per build: its own object directory, the library's translation units compiled in parallel)
-  make -s -j4 lib LIB=build/explib/libdetexhip_exp_$name.so OBJDIR=build/obj_exp/$name EXTRA_HIPFLAGS="$extra -DDETEXHIP_TUNE_HEADER='\"$hdr\"'" &
+  make -s -j4 lib LIB=build/explib/libdetexhip_exp_$name.so OBJDIR=build/obj_exp/$name ${srcs:+SRCS_HIP="$srcs"} EXTRA_HIPFLAGS="-DDETEXHIP_TUNE_HEADER='\"$hdr\"'" &
 done
 wait
 ls -la build/explib

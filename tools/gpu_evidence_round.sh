@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-4 measurement round on the GPU box (via gpurun): what is committed under profiles/r04/ from the FINAL library comes from here.
+# The final measurement round of a build round on the GPU box (via gpurun):  bash tools/gpu_evidence_round.sh r05  -> gpurun_out/r05/, whose
+# summaries are then committed under profiles/r05/ (what profiles/rNN/ holds from the FINAL library of a round comes from here).
 set -u
 export TMPDIR=/tmp
-OUT=gpurun_out/round4
+TAG=${1:-round}
+OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 ROOT=$(pwd)
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s 2>&1 | tail -14 | tee $OUT/pytest_gpu.log
@@ -17,10 +19,10 @@ timeout 900 python bench.py --no-cpu --no-extras --formats-json $OUT/formats_819
 timeout 900 python bench.py --no-cpu --no-extras --layout tiled --formats-json $OUT/formats_8192_tiled.json > /dev/null 2> $OUT/formats_tiled.err; grep -c launch_us $OUT/formats_tiled.err
 echo "== N=2 plumbing over gloo on this one GPU: the 32768^2 BC1 image in two bands, every rank digests its band (eighths) against the reference"
 DETEX_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --strong-image 32768 --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/bench_n2_gloo_32768.json 2> $OUT/bench_n2_gloo.err; cut -c1-400 $OUT/bench_n2_gloo_32768.json; tail -2 $OUT/bench_n2_gloo.err
-python - <<'PY'
-import json
+python - $TAG <<'PY'
+import json, sys
 try:
-    d = json.loads(open("gpurun_out/round4/bench_n2_gloo_32768.json").read().strip().splitlines()[-1])
+    d = json.loads(open("gpurun_out/%s/bench_n2_gloo_32768.json" % sys.argv[1]).read().strip().splitlines()[-1])
     print("N=2 gloo: value", d["value"], "digests match on all ranks:", d.get("whole_band_digests_match_reference_all_ranks"))
 except Exception as e:
     print("N=2 gloo line unreadable:", e)
