@@ -12,7 +12,9 @@ HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include
 
 all: lib oracle ubench c-client
 lib: $(LIB)
-ubench: tools/ubench/valu_rates tools/ubench/host_latency hbmref
+ubench: tools/ubench/valu_rates tools/ubench/host_latency tools/ubench/host_midsize hbmref
+tools/ubench/host_midsize: tools/ubench/host_midsize.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -pthread -o $@ $<
 tools/ubench/host_latency: tools/ubench/host_latency.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -o $@ $<
 tools/ubench/valu_rates: tools/ubench/valu_rates.hip
@@ -70,10 +72,10 @@ c-client: $(CLIENT) $(if $(wildcard $(REFHDR)/detex.h),$(CLIENT)_refhdr) $(if $(
 # the same program over the COMPILED REFERENCE (oracle/_ref, where it has been built): bench.py's like-for-like CPU figure for the small calls
 $(CLIENT)_reflib: $(CLIENT).c include/detex.h oracle/_ref/libdetex_ref.so
 	gcc -std=c99 -O2 -Wall -Wextra -Iinclude -o $@ $< -Loracle/_ref -ldetex_ref -Wl,-rpath,'$$ORIGIN/../../oracle/_ref'
-$(CLIENT): $(CLIENT).c include/detex.h $(LIB)
-	gcc -std=c99 -O2 -Wall -Wextra -Iinclude -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
-$(CLIENT)_refhdr: $(CLIENT).c $(REFHDR)/detex.h $(LIB)
-	gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O2 -Wall -I$(REFHDR) -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
+$(CLIENT): $(CLIENT).c include/detex.h include/detexhip.h $(LIB)
+	gcc -std=c99 -O2 -Wall -Wextra -DWITH_DETEXHIP -Iinclude -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
+$(CLIENT)_refhdr: $(CLIENT).c $(REFHDR)/detex.h include/detexhip.h $(LIB)
+	gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O2 -Wall -DWITH_DETEXHIP -I$(REFHDR) -Iinclude -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
 
 oracle:
 	$(MAKE) -C oracle all

@@ -14,7 +14,7 @@ prints ONE JSON line on rank 0.
             (splitmix64, tests/oracle_lib.py).  Extra keys: `per_format` (the six headline formats
             of configs[1..4] at 8192^2, streams U/M/C, plus the weakest kernels -- signed BC6H,
             block-major BC7, RGTC1 -- each timed at steady state), `beyond_mall`,
-            `per_format.beyond_cache_16384` (the six headline formats at 16384^2), `cold` (first launch after idle, mean of the first
+            `per_format.beyond_cache_16384` (the six headline formats, and the five formats whose 8192^2 footprint fits the Infinity Cache, at 16384^2), `cold` (first launch after idle, mean of the first
             twenty, the contract's W + K started cold), `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`,
             `host_tier_small` (per-call latency of small textures / one block through the host API,
             beside the reference on one host thread), `cpu_baseline`.
@@ -28,7 +28,9 @@ prints ONE JSON line on rank 0.
             BPTC_FLOAT -> FLOAT_RGBX16, 32768^2 over the ranks, decode-only + its gathers, rank 0's
             EVERY rank's whole band checked against the reference's digests, as is every rank's band of the headline image:
             `whole_band_digests_match_reference_all_ranks`), `rccl_ranks` (ranks that answered an all_reduce; the run exits with
-            code 5 unless that is N, one rank per distinct GPU).  --weak restores the round-1 line.
+            code 5 unless that is N, one rank per distinct GPU).  --weak restores the round-1 line.  DETEX_BENCH_FORCE_DIST=1 takes
+            this whole branch at ANY world size: with WORLD_SIZE 1 it is the RCCL pre-flight a one-GPU box can run (nccl process
+            group, rank census, barriers, whole-image digests, both gathers, BC6H 32768^2): tests/test_gpu_rccl_preflight.py.
   roofline  algorithmic bytes per launch (blocks * (block_bytes + 16*pixel_bytes)) / average
             launch duration from HIP events recorded on the launch stream around the timed
             region; peak = 8 TB/s (MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from
@@ -60,6 +62,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0
 HEADLINE_FORMATS = ["BC1", "BC3", "BPTC", "ETC2", "ETC2_EAC", "BPTC_FLOAT"]
+# formats whose 8192^2 footprint (blocks + pixels) fits the 256 MiB Infinity Cache: their HBM rate is measured at 16384^2 (384-768 MiB)
+NARROW_FORMATS = ["RGTC1", "RGTC2", "SIGNED_RGTC1", "EAC_R11", "EAC_SIGNED_R11"]
 # the kernels furthest below the roofline / with the shortest launches, reported beside the headline formats: (format, stream, layout)
 # (stream F: signed BC6H has no fixture in the reference; the unsigned format's fixture, whose blocks are valid signed blocks too, stands in for
 # coherent encoder-made content)
@@ -260,28 +264,34 @@ def main():
     device_index = local_rank if (backend == "nccl" and local_rank < ndev) else local_rank % ndev
     torch.cuda.set_device(device_index)
     rccl_ranks = 1
-    if world > 1:
+    # DETEX_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, rank census, barriers, band digests, both gathers) at ANY world size
+    # -- with WORLD_SIZE 1 and the nccl backend this is the pre-flight of the RCCL path on a one-GPU box (tests/test_gpu_rccl_preflight.py)
+    multi = world > 1 or os.environ.get("DETEX_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())          # ranks the collective library actually reached
-        # one rank per GPU, every rank reached: anything else is not the N-GPU measurement the line would claim -- fail loudly
+        os.environ.setdefault("MASTER_PORT", "29500")
+        # The census comes FIRST and travels over gloo (CPU tensors of a mixed-backend group): which GPU each rank sits on, by PCI address.
+        # Two ranks on one GPU -- torchrun --nproc-per-node N on a box with fewer GPUs -- would make RCCL abort inside its communicator
+        # set-up ("Duplicate GPU detected"); found here, before any RCCL call, the run ends with a message and exit code 5 instead.
+        dist.init_process_group("cpu:gloo,cuda:nccl" if backend == "nccl" else backend, rank=rank, world_size=world)
         prop = torch.cuda.get_device_properties(device_index)
-        mine = torch.tensor([device_index, getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1), getattr(prop, "pci_domain_id", -1)],
-                            dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        mine = torch.tensor([device_index, getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1), getattr(prop, "pci_domain_id", -1)], dtype=torch.int64)
         seen = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         places = [tuple(int(v) for v in t.tolist()) for t in seen]
         # distinct GPUs: by PCI address where the runtime reports one, else by device index (which then must not have been folded)
         by_pci = all(p[1] >= 0 for p in places)
         distinct = len({p[1:] for p in places}) == world if by_pci else (len({p[0] for p in places}) == world and world <= ndev)
-        if backend == "nccl" and (rccl_ranks != world or args.gpus != world or not distinct):
-            log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, ranks reached by the all_reduce %d, visible devices %d, "
-                "(device, pci bus, pci device, pci domain) per rank %s" % (rank, args.gpus, world, rccl_ranks, torch.cuda.device_count(), places))
+        if backend == "nccl" and (args.gpus != world or not distinct):
+            log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, visible devices %d, (device, pci bus, pci device, pci domain) per rank %s"
+                % (rank, args.gpus, world, torch.cuda.device_count(), places))
+            dist.destroy_process_group()
+            sys.exit(5)
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)                  # (the first CUDA collective: RCCL builds its communicator here)
+        rccl_ranks = int(ones.item())          # ranks the collective library actually reached
+        if backend == "nccl" and rccl_ranks != world:
+            log("bench.py: rank %d: the all_reduce reached %d of %d ranks" % (rank, rccl_ranks, world))
             dist.destroy_process_group()
             sys.exit(5)
     binding.load()
@@ -290,8 +300,11 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if multi:
+            if backend == "nccl":
+                dist.barrier(device_ids=[device_index])      # (over RCCL, on this rank's GPU -- not the gloo half of the mixed-backend group)
+            else:
+                dist.barrier()
             torch.cuda.synchronize()
 
     TARGETS = {"BGRA8": F.PIXEL_FORMAT_BGRA8, "BGRX8": F.PIXEL_FORMAT_BGRX8, "RGB8": F.PIXEL_FORMAT_RGB8,
@@ -350,7 +363,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
-        if world > 1:
+        if multi:
             t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, ev_ms = t.tolist()
@@ -388,11 +401,14 @@ def main():
 
     def roofline_of(job, launch_us, clocks=True):
         ach = job.alg_bytes / (launch_us * 1e-6) / 1e9
+        resident = bool(job.alg_bytes <= MALL_BYTES)
+        # (a footprint that fits the Infinity Cache is not served from HBM: no HBM fraction is claimed for it -- frac is null, the rate stays)
         row = {"launch_us": round(launch_us, 2), "gpixel_s": round(job.W * job.H / (launch_us * 1e-6) / 1e9, 1),
-               "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
-               "footprint_MiB": round(job.alg_bytes / 2 ** 20, 1), "cache_resident": bool(job.alg_bytes <= MALL_BYTES)}
-        if row["cache_resident"]:
-            row["frac_note"] = "blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s)"
+               "achieved_GBps": round(ach, 1), "frac": None if resident else round(ach / HBM_PEAK_GBPS, 4),
+               "footprint_MiB": round(job.alg_bytes / 2 ** 20, 1), "cache_resident": resident}
+        if resident:
+            row["frac_note"] = ("blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s) and no roofline fraction is given; "
+                                "per_format.beyond_cache_16384 has this format at a size that does not fit")
         if clocks:                         # shader clock and board power while this kernel runs back to back (0.15 s, hwmon files)
             t = telemetry.during(job.step)
             torch.cuda.synchronize()
@@ -435,7 +451,7 @@ def main():
     fmt = F.BY_NAME[args.format]
     # (plumbing runs over gloo move CUDA tensors through the host at ~0.03 GB/s point-to-point: they get small images)
     big = 32768 if backend == "nccl" else 2048
-    strong = args.strong_image if args.strong_image is not None else (0 if (world == 1 or args.weak) else big)
+    strong = args.strong_image if args.strong_image is not None else (0 if (not multi or args.weak) else big)
     W = H = args.size
     if args.band_height:
         H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
@@ -498,8 +514,8 @@ def main():
     achieved = job.alg_bytes / (launch_ms * 1e-3) / 1e9
 
     # what every rank just wrote, checked against the CPU oracle on a bounded sample; AND over ranks
-    verified_rows = job.verify(64 if world == 1 else 16)
-    if world > 1:
+    verified_rows = job.verify(16 if multi else 64)
+    if multi:
         v = torch.tensor([verified_rows], dtype=torch.int32, device=coll_dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified_rows = int(v.item())
@@ -528,12 +544,12 @@ def main():
         mine = band_digests_match(fmt, strong, shard, job.d_out)
         if mine is not None:
             flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=coll_dev)
-            if world > 1:
+            if multi:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             extras["whole_band_digests_match_reference_all_ranks"] = bool(flag.item())
             if not mine:
                 log("bench.py: rank %d: WHOLE-BAND DIGEST MISMATCH against the compiled reference" % rank)
-    if world > 1 and not args.no_extras:
+    if multi and not args.no_extras:
         def time_gathers(f, side, sh, band, reps=2):
             """the optional whole-image gather, timed separately from the decode (never part of `value`): to ONE rank with grouped
             point-to-point sends (the root's links to all peers busy at once, nothing lands elsewhere) and to EVERY
@@ -613,7 +629,7 @@ def main():
             del wjob
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -645,7 +661,7 @@ def main():
     if verified_rows == 0 or extras.get("whole_band_digests_match_reference_all_ranks") is False:
         log("bench.py: OUTPUT MISMATCH against the oracle / the reference's band digests")
         result["value"] = 0.0
-    if world == 1 and not args.no_extras:
+    if not multi and not args.no_extras:
         t = telemetry.during(job.step)
         torch.cuda.synchronize()
         if t:
@@ -660,7 +676,7 @@ def main():
         if ref.get("ref_copy_GBps"):
             result["roofline"]["frac_of_measured_copy"] = round(achieved / ref["ref_copy_GBps"], 4)
     live = None
-    if world == 1 and not args.no_extras and not args.target and W == H and args.stream == "U":
+    if not multi and not args.no_extras and not args.target and W == H and args.stream == "U":
         live = live_pmc_traffic(fmt.name, W, args.layout)
     if live:
         result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
@@ -672,12 +688,17 @@ def main():
         if t:
             result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
             result["roofline"]["traffic_source"] = "REPLAYED from profiles/pmc_traffic.json (no live counter pass in this run): " + str(t.get("source"))
-    if world > 1:
+    if multi:
         result["rccl_ranks"] = rccl_ranks
+        result["forced_dist_path"] = bool(world == 1)            # DETEX_BENCH_FORCE_DIST=1: the N > 1 code path at world size 1 (pre-flight, not a scaling point)
+        try:
+            result["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:  # noqa
+            result["rccl_version"] = None
         result["collective_backend"] = backend
     result.update(extras)
 
-    if world == 1:
+    if not multi:
         # host-pointer drop-in tier (PCIe-inclusive; never `value`)
         try:
             if args.layout != "linear":
@@ -693,7 +714,7 @@ def main():
         except Exception as e:  # noqa
             log("host tier timing failed:", e)
 
-    if world == 1 and not args.no_extras and not args.formats_json:
+    if not multi and not args.no_extras and not args.formats_json:
         # per-format table of the headline formats (BASELINE configs[1..4]) at 8192^2, steady state, streams U / M / C
         table = {}
         t_start = time.perf_counter()
@@ -723,16 +744,21 @@ def main():
         torch.cuda.empty_cache()
         if result["roofline"].get("ref_copy_GBps"):     # a mixed read + write stream: beside the 8 TB/s fraction, the fraction of the copy measured in this process
             for row in table.values():
-                row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
+                if not row["cache_resident"]:
+                    row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
         # the six headline formats beyond the Infinity Cache: 16384^2 (1 GiB of 32-bit pixels, 2 GiB of BC6H's)
         big_table = {}
-        for name in HEADLINE_FORMATS:
+        for name in HEADLINE_FORMATS + NARROW_FORMATS:
             try:
                 f = F.BY_NAME[name]
                 j = Job(f, 16384, 16384, make_input(f, 4096, 4096, "U"))
                 us, launches = steady_state_us(j, window=25, max_windows=8, min_launches=100)
                 row = roofline_of(j, us)
                 row["launches_before_reading"] = launches
+                tr = pmc_traffic("%s/16384/linear" % name)
+                if tr:
+                    row["traffic"] = tr["hbm_bytes_per_launch"]
+                    row["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / j.alg_bytes, 4)
                 big_table["%s/U" % name] = row
                 del j
             except Exception as e:  # noqa
@@ -740,7 +766,7 @@ def main():
             torch.cuda.empty_cache()
         if result["roofline"].get("ref_copy_GBps"):
             for row in big_table.values():
-                if "achieved_GBps" in row:
+                if "achieved_GBps" in row and not row["cache_resident"]:
                     row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
         result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran); "
                                                              "sclk_mhz / power_w: hwmon samples while the kernel then runs back to back for 0.15 s; cache_resident: "
@@ -769,7 +795,7 @@ def main():
             log("strong_image_32768 failed:", e)
         torch.cuda.empty_cache()
 
-    if world == 1 and not args.no_extras:
+    if not multi and not args.no_extras:
         # small inputs through the reference's own entry points (host pointers): where the PCIe-attached decoder loses to one
         # host thread.  Per call, including the ctypes call overhead on both sides (~2 us).
         try:
@@ -829,10 +855,10 @@ def main():
         except Exception as e:  # noqa
             log("host_tier_small failed:", e)
 
-    if world == 1 and not args.no_cpu:
+    if not multi and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(fmt, data, W, H)
 
-    if args.formats_json and world == 1:
+    if args.formats_json and not multi:
         table = {}
         for f in F.FORMATS:
             for kind in ["U", "M", "C"]:
@@ -851,7 +877,7 @@ def main():
         json.dump(table, open(args.formats_json, "w"), indent=1, sort_keys=True)
 
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -437,7 +437,7 @@ DH void bc7_decode_with(uint4 blk, uint32_t rec_index, uint32_t flags, uint32_t 
 	// there.  Each window then gets the anchors' absent top bits inserted as zeros (w + (w & himask) doubles the
 	// part of w at and above the insertion point), after which texel k of a window sits at bit k*ib.
 	Group g_ci = L.template group<F_ROW_C / 4>();		// row_c, pos_c, ibc, imask_c
-	Group g_cw = L.template group<F_WMUL_C / 4>();		// wmul_c, wadd_c, sel_ba, half_a
+	Group g_cw = L.template group<F_WMUL_C / 4>();		// wmul_c, wadd_c, sel_comb (F_SEL_COMB), half_a
 	L.pin(g_ci, g_cw);
 	uint32_t c0, c1;
 	lane.field64(g_ci.x, g_ci.y, c0, c1);

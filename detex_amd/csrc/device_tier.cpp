@@ -134,7 +134,13 @@ extern "C" int detexhipGetDeviceCount(void) {
 
 extern "C" void detexhipReleaseThreadResources(void) { release_thread_context(); release_shard_slots(); }
 
-extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.3 (gfx950; detex v0.1.2 block-decode ABI)"; }
+extern "C" const char *detexhipVersion(void) { return "libdetexhip 0.4 (gfx950; detex v0.1.2 block-decode ABI; extension ABI 4)"; }
+extern "C" int detexhipCheckAbi(int compiled_against) {
+	if (compiled_against == DETEXHIP_ABI_VERSION) return 0;
+	detexSetErrorMessage("libdetexhip: the caller was compiled against extension ABI %d, this library implements %d (struct layouts of detexhip.h differ)", compiled_against,
+		DETEXHIP_ABI_VERSION);
+	return 1;
+}
 
 extern "C" void detexhipSetQuirks(uint32_t quirks) { thread_settings().quirks = (int)(quirks & DETEXHIP_QUIRKS_REFERENCE); }
 extern "C" uint32_t detexhipGetQuirks(void) { (void)current_spec_flags(); return (uint32_t)thread_settings().quirks; }

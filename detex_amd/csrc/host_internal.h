@@ -47,6 +47,7 @@ struct Geometry {
 struct BatchArgs {
 	const void *blocks; void *pixels; size_t n; uint32_t mode_mask, flags; uint8_t *ok; uint32_t *status;
 	hipStream_t stream; bool checked; int epi; int resident;
+	Completion completion;	// {done != nullptr}: the small-batch kernel of the host tier (kernels_extra.h: decode_blocks_direct), which publishes it
 };
 // one block handed over as a kernel argument (kernels_extra.h: decode_single)
 struct SingleArgs { const uint8_t *bitstring; uint32_t mode_mask, flags; uint32_t *pixels; uint8_t *ok; hipStream_t stream; int epi; uint32_t *done; uint32_t ticket; };

@@ -42,6 +42,10 @@ int resident_idle_microseconds() {
 bool ResidentService::wanted(const FormatEntry *fmt, int epilogue) {
 	const bool repeat = fmt != nullptr && prev_f == fmt && prev_epi == epilogue;
 	prev_f = fmt; prev_epi = epilogue;
+	// A call that does not continue the row ends the running instance NOW (a stop request and its answer: one round trip across the
+	// link) instead of leaving it to spin out its idle time: what such a call does next -- hipMalloc / hipFree of staging buffers, a
+	// table upload -- synchronises with the device and would wait behind that kernel, as would other streams sharing its hardware queue.
+	if (!repeat && launched) (void)stop();
 	if (!repeat || broken || resident_idle_microseconds() <= 0) return false;
 	int device = 0;
 	if (hipGetDevice(&device) != hipSuccess) return false;
@@ -56,10 +60,9 @@ bool ResidentService::prepare(int device) {
 	auto make = [&]() -> bool {
 		HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
 		void *h = nullptr, *d = nullptr;
-		if (hipHostMalloc(&h, kBufferBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-			(void)hipGetLastError();
-			HIP_TRY(hipHostMalloc(&h, kBufferBytes, hipHostMallocMapped), "hipHostMalloc");
-		}
+		// (coherent pinned memory or no service: with non-coherent memory the kernel's polls and the host's view of `done` / `state` are
+		// not guaranteed to meet, and the calls would only be rescued by their timeouts)
+		HIP_TRY(hipHostMalloc(&h, kBufferBytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(coherent)");
 		h_buf = static_cast<uint8_t *>(h);
 		HIP_TRY(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
 		d_buf = static_cast<uint8_t *>(d);

@@ -49,6 +49,30 @@ DH void publish_completion(const Completion &c) {
 	}
 }
 
+// ---- a small batch of independent blocks for the host tier's batched per-block call (include/detexhip.h: detexhipDecompressBlocks; the
+// loop a client of the leaf functions detex.h:435-531 would otherwise write): blocks, pixels, ok bytes and the status word all live in
+// pinned host memory, mode_mask and flags are honoured per block exactly as the leaf functions do, output is block-major (a lane's
+// 16-byte stores fill its block's 64 / 128 contiguous bytes), and the last workgroup releases the completion word the caller polls.
+// Batches too large for the pinned exchange go through decode_blocks<.., CHECKED = true> on device buffers instead.
+template <class Dec, int EPI>
+__global__ __launch_bounds__(256) void decode_blocks_direct(const void *__restrict__ blocks, uint8_t *__restrict__ pixels, uint32_t n_blocks, uint32_t mode_mask,
+		uint32_t flags, uint8_t *__restrict__ ok_out, uint32_t *__restrict__ status, const Completion completion) {
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
+	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n_blocks) {
+		uint32_t o[4 * ROW];
+		const bool ok = decode_block<Dec, EPI, true>(blocks, i, mode_mask, flags, o);
+		u32x4 *out = reinterpret_cast<u32x4 *>(pixels) + (uint64_t)i * ROW;
+#pragma unroll
+		for (int k = 0; k < ROW; k++) out[k] = u32x4{ o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3] };
+		ok_out[i] = ok ? 1 : 0;
+		raise_status(!ok, status);
+	}
+	publish_completion(completion);
+}
+
 // one workgroup's 256 blocks of one level; `fetch(i)` delivers block i (from the level's stream, or a word the caller already holds)
 template <class Dec, int EPI, class Fetch> DH void decode_level_tile_from(const LevelDesc &lv, uint32_t i, uint32_t *__restrict__ status, uint32_t decode_flags, Fetch &&fetch) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;

@@ -57,6 +57,25 @@ DH uint32_t resident_leader_step(const ResidentArgs &a, const u32x4 (&c)[4], uin
 	return 2u;
 }
 
+// A request for more than one tile is acknowledged by EVERY workgroup of the instance -- those without a tile of it as well -- and the
+// last of the kResidentWorkgroups acknowledgements publishes `done`: the host posts its next request only after `done`, so the
+// leader cannot overwrite the payload in words[4..15] while a slow follower is still copying it, and a follower that wakes up late
+// cannot run with a stale request number and a newer payload.  The counter (words[2..3] as ONE 64-bit word) carries its request:
+// {instance, request number} << 2 | acknowledgements so far -- what a previous request or a previous instance left there (an
+// instance that went away before all of its workgroups had answered) has another key and is simply replaced.  (thread 0 only)
+DH bool resident_acknowledge(const ResidentArgs &a, uint32_t seq) {
+	unsigned long long *word = reinterpret_cast<unsigned long long *>(a.words + 2);
+	const unsigned long long key = ((unsigned long long)(a.instance & 0x3FFFFFFFu) << 32 | seq) << 2;
+	unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for (;;) {
+		const bool mine = (seen & ~3ull) == key;
+		const bool last = mine && (seen & 3ull) == kResidentWorkgroups - 1u;
+		const unsigned long long next = last ? 0ull : (mine ? seen + 1ull : key | 1ull);
+		if (__hip_atomic_compare_exchange_strong(word, &seen, next, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return last;
+	}
+}
+static_assert(kResidentWorkgroups == 4, "resident_acknowledge counts to four in two bits");
+
 // the other workgroups, thread 0: wait for the leader
 DH void resident_wait_leader(const ResidentArgs &a, uint32_t last, uint64_t t_start, uint32_t *s_req) {
 	for (;;) {
@@ -143,10 +162,11 @@ __global__ __launch_bounds__(256) void decode_resident(const ResidentArgs a) {
 				else blk = Word{ t0.x, t0.y };
 			} else {
 				n_tiles = lv.n_blocks > 256u ? (lv.n_blocks + 255u) / 256u : 1u;
-				if (blockIdx.x >= n_tiles) continue;		// (workgroup-uniform) woken for a texture with fewer tiles than workgroups
 				blk = load_block<Dec>(lv.blocks, i < lv.n_blocks ? i : 0u);
 			}
-			if (block_major) {
+			if (blockIdx.x >= n_tiles) {
+				// (workgroup-uniform) woken for a texture with fewer tiles than workgroups: nothing to decode, but acknowledged below
+			} else if (block_major) {
 				if (i < lv.n_blocks) {
 					uint32_t o[4 * ROW];
 					const bool ok = decode_word<Dec, EPI, false>(blk, 0xFFFFFFFFu, q[5], o);
@@ -162,11 +182,7 @@ __global__ __launch_bounds__(256) void decode_resident(const ResidentArgs a) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");	// system scope: this thread's stores are on their way to host memory
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			bool publish = n_tiles <= 1u;
-			if (!publish && __hip_atomic_fetch_add(a.words + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_tiles) {
-				__hip_atomic_store(a.words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				publish = true;
-			}
+			const bool publish = n_tiles <= 1u || resident_acknowledge(a, seq);
 			if (publish) __hip_atomic_store(&a.mail->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			me.t_last = wall_clock64();
 		}

@@ -144,7 +144,10 @@ template <class Dec> hipError_t launch_linear(const Geometry &g) {
 template <class Dec, int EPI> hipError_t launch_blocks_epi(const BatchArgs &a) {
 	const uint32_t tiles = (uint32_t)((a.n + 255u) / 256u);
 	uint8_t *px = static_cast<uint8_t *>(a.pixels);
-	if (a.checked) {
+	if (a.completion.done != nullptr) {		// host tier, small batch: everything in pinned host memory, completion word polled by the caller
+		hipLaunchKernelGGL((decode_blocks_direct<typename PlainDecoder<Dec>::type, EPI>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n,
+			a.mode_mask, a.flags, a.ok, a.status, a.completion);
+	} else if (a.checked) {
 		hipLaunchKernelGGL((decode_blocks<typename PlainDecoder<Dec>::type, EPI, true>), dim3(tiles), dim3(256), 0, a.stream, a.blocks, px, (uint32_t)a.n,
 			a.mode_mask, a.flags, a.ok, a.status);
 	} else {

@@ -2,6 +2,7 @@
 // an optional peer-copy gather.  Host code only.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 
@@ -87,9 +88,17 @@ hipError_t grow(void **buf, size_t *cap, size_t need) {		// on the current devic
 // gather).  Returns true if `device` can address `peer`'s memory directly -- the copy then travels over the link between the two
 // (xGMI on an MI355X node) -- and false where the topology or the runtime does not allow it; only SUCCESS is remembered as such, a
 // pair that failed is asked about again by the next call.
+// DETEXHIP_PEER_ACCESS=0 in the environment: no pair is mapped -- not even a device with itself -- and every gather copy goes the way of an
+// unmapped pair (hipMemcpyPeerAsync, which the runtime stages; padded bands row by row).  For nodes whose peer mappings misbehave,
+// and the only way to run that branch on a box with one GPU (tests/test_gpu_host_multi.py).
 std::mutex g_peer_mutex;
 uint64_t g_peer_enabled[64];
+bool peer_mapping_allowed() {
+	static const bool allowed = [] { const char *env = getenv("DETEXHIP_PEER_ACCESS"); return !(env && env[0] == '0'); }();
+	return allowed;
+}
 bool peer_access(int device, int peer) {			// `device` is current
+	if (!peer_mapping_allowed()) return false;
 	if (device == peer) return true;
 	if (device < 0 || device >= 64 || peer < 0 || peer >= 64) return false;
 	std::lock_guard<std::mutex> lock(g_peer_mutex);
@@ -130,7 +139,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_forma
 	(void)hipGetDevice(&prev);
 	int rc = 0;
 	auto fail = [&](const char *what, hipError_t e) { detexSetErrorMessage("%s: %s failed: %s", who, what, hipGetErrorString(e)); rc = 1; };
-	for (int g = 0; g < n_shards; g++) t_shards.slot[g].used = false;
+	for (int g = 0; g < n_shards; g++) { t_shards.slot[g].used = false; shards[g].peer_access = -1; }	// (out fields of shards an early failure never reaches)
 	// per-shard rows, streams, status words, uploads, conversion tables (all before the timed region)
 	for (int g = 0; g < n_shards && rc == 0; g++) {
 		detexhipShard &sh = shards[g];

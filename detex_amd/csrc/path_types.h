@@ -73,7 +73,8 @@ struct ResidentMail {
 	uint32_t status, pad2[15];			// host zeroes it with a request; the kernel raises it for a failed block
 };
 // `words` (device memory, zeroed once): [0] number of the request the leading workgroup handed to the others, [1] the instance that
-// has left, [2] the workgroups' completion counter, [4..15] that request's payload
+// has left, [2..3] the workgroups' acknowledgement counter, keyed by instance and request (kernels_resident.h: resident_acknowledge),
+// [4..15] that request's payload
 struct ResidentArgs {
 	ResidentMail *mail; const void *blocks; uint8_t *pixels; uint32_t *words;
 	uint32_t start_seq, instance; uint64_t idle_ticks, max_ticks;	// ticks of the constant 100 MHz-class clock (wall_clock64)

@@ -37,6 +37,12 @@ DETEXHIP_API int detexhipGetDeviceCount(void);
 DETEXHIP_API int detexhipSetDevice(int device);
 DETEXHIP_API void detexhipReleaseThreadResources(void);
 DETEXHIP_API const char *detexhipVersion(void);
+/* The extension API's structs grow now and then (detexhipShard gained `peer_access` in 0.3 -> ABI 4): a client passes the
+ * DETEXHIP_ABI_VERSION it was COMPILED with and gets 0 if this library lays the structs out the same way, non-zero (and an error
+ * message) otherwise -- check once at start-up instead of having an array of shards read at the wrong stride.  The reference-tier
+ * entry points of detex.h are not affected (their ABI is the reference's and does not change). */
+#define DETEXHIP_ABI_VERSION 4
+DETEXHIP_API int detexhipCheckAbi(int compiled_against);
 /* The smallest host-pointer calls (one block: detexDecompressBlock*, detex.h:435-531 / texture.c:55-70; textures of up to
  * 1024 blocks, linear or block-major: texture.c:77-145) cost a kernel launch and its completion each -- 7 us / 11 us on the test box against the
  * reference's 3 us / 9 us on one host thread.  From the SECOND such call in a row of one (texture format, pixel format) pair on, the
@@ -139,6 +145,21 @@ DETEXHIP_API int detexhipDecompressTextureTiledDevice(uint32_t texture_format, c
  * (uint8_t, optional) receives the leaf function's bool; failed blocks are zero-filled. */
 DETEXHIP_API int detexhipDecompressBlocksDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks,
 	uint32_t mode_mask, uint32_t flags, void *d_pixels, uint8_t *d_ok, void *stream);
+
+/* The same on HOST pointers: the migration path of a client that loops over the leaf functions.  In the reference one
+ * detexDecompressBlock<FMT> call (detex.h:435-531, e.g. decompress-bc.c:23-61) costs 0.03 us; here every call is a trip to the GPU
+ * (5-8 us), and always will be -- so the loop
+ *         for (i = 0; i < n; i++) ok &= detexDecompressBlockBC1(blocks + 8 * i, mode_mask, flags, pixels + 64 * i);
+ * becomes ONE call
+ *         ok = detexhipDecompressBlocks(DETEX_TEXTURE_FORMAT_BC1, blocks, n, mode_mask, flags, pixels, NULL);
+ * blocks: n_blocks blocks of 8 / 16 bytes back to back (no alignment required); pixels: 16 pixels per block in the format's native pixel
+ * format, block after block (what the leaf functions write); ok: optional, n_blocks bytes, ok[i] = the leaf function's bool for block i.
+ * mode_mask and flags apply to every block, exactly as the leaf functions interpret them.  A failed block is zero-filled (the leaf
+ * functions leave the caller's buffer in an unspecified state there).  Returns true if every block decoded, else false with the
+ * reference's error text (the texture drivers' convention, texture.c:125-128,144); false without touching ok on usage / HIP errors.
+ * Synchronous, per-thread state only, re-entrant like the rest of the host tier.  (INTEGRATION.md section 6 has the measured crossover.) */
+DETEXHIP_API bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks,
+	uint32_t mode_mask, uint32_t flags, uint8_t *pixels, uint8_t *ok);
 
 /* ---- mip-chain batching -------------------------------------------------------
  * Every level of a mip chain (what detexLoadKTXFileWithMipmaps returns as separate textures,

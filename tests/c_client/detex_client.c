@@ -9,8 +9,11 @@
  *                                                        FORMAT (detex.h:613-727), decoded and digested the same way
  *   detex_client --sha256-selftest       digest of "abc" and of 1,000,000 'a' (FIPS 180-4 vectors)
  *   detex_client --latency               microseconds per call (median of 2000) of detexDecompressBlockBC1 and of
- *                                        detexDecompressTextureLinear on 64x64 ... 1024x1024 BC1 textures: what a C caller pays, without
- *                                        the ctypes overhead bench.py's host_tier_small carries
+ *                                        detexDecompressTextureLinear on 64x64 ... 4096x4096 BC1 and BC7 textures: what a C caller pays,
+ *                                        without the ctypes overhead bench.py's host_tier_small carries
+ *   detex_client --blocks                n = 1, 1024, 1048576 independent blocks (BC1, BC7): the loop over the leaf function
+ *                                        (detex.h:435-531) against ONE detexhipDecompressBlocks call (libdetexhip builds only:
+ *                                        -DWITH_DETEXHIP), results compared block by block
  */
 #define _POSIX_C_SOURCE 200809L
 #include <stdint.h>
@@ -20,6 +23,10 @@
 #include <time.h>
 
 #include "detex.h"
+#ifdef WITH_DETEXHIP
+#define DETEXHIP_COMPAT_DETEX_H		/* (a detex.h is already included: this repository's or the reference's) */
+#include "detexhip.h"
+#endif
 
 /* ---- sha256 (FIPS 180-4), written for this test ------------------------------------------------------------------------------ */
 static const uint32_t K256[64] = {
@@ -110,32 +117,99 @@ static int latency(void) {
 	}
 	qsort(t, N, sizeof t[0], cmp_double);
 	printf("latency one_block_us=%.2f p90=%.2f\n", t[N / 2], t[N * 9 / 10]);
-	for (int side = 64; side <= 1024; side *= 2) {
-		const int n = side <= 256 ? N : 300;			/* (the large ones take 0.1-1.5 ms per call on the CPU) */
-		const size_t nb = (size_t)(side / 4) * (side / 4), out_bytes = (size_t)side * side * 4;
-		uint8_t *blocks = (uint8_t *)malloc(nb * 8), *pixels = (uint8_t *)malloc(out_bytes), *expect = (uint8_t *)malloc(out_bytes);
-		for (size_t k = 0; k < nb * 8; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
-		detexTexture tex;
-		tex.format = DETEX_TEXTURE_FORMAT_BC1; tex.data = blocks; tex.width = side; tex.height = side; tex.width_in_blocks = side / 4; tex.height_in_blocks = side / 4;
-		for (int i = -WARM; i < n; i++) {
-			blocks[4] = (uint8_t)i;
-			const double t0 = now_us();
-			if (!detexDecompressTextureLinear(&tex, pixels, DETEX_PIXEL_FORMAT_RGBA8)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
-			if (i >= 0) t[i] = now_us() - t0;
-			if (i == -WARM) memcpy(expect, pixels, out_bytes);
-			else if (((i + WARM) & 255) == 0 && memcmp(expect, pixels, out_bytes) != 0) wrong++;
-			else if (((i + WARM) & 255) == 1 && memcmp(expect, pixels, 64) == 0) wrong++;
+	for (int f = 0; f < 2; f++) {
+		const uint32_t format = f ? DETEX_TEXTURE_FORMAT_BPTC : DETEX_TEXTURE_FORMAT_BC1;
+		const size_t bs = f ? 16 : 8;
+		for (int side = 64; side <= 4096; side *= 2) {
+			const int n = side <= 256 ? N : (side <= 1024 ? 300 : 40);	/* (the large ones take 0.1-25 ms per call on the CPU) */
+			const int warm = side <= 1024 ? WARM : 8;
+			const size_t nb = (size_t)(side / 4) * (side / 4), out_bytes = (size_t)side * side * 4;
+			uint8_t *blocks = (uint8_t *)malloc(nb * bs), *pixels = (uint8_t *)malloc(out_bytes), *expect = (uint8_t *)malloc(out_bytes);
+			for (size_t k = 0; k < nb * bs; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
+			if (f) for (size_t k = 0; k < nb; k++) blocks[k * bs] |= 1;		/* BC7: every block valid (mode 0), so the call returns true */
+			detexTexture tex;
+			tex.format = format; tex.data = blocks; tex.width = side; tex.height = side; tex.width_in_blocks = side / 4; tex.height_in_blocks = side / 4;
+			for (int i = -warm; i < n; i++) {
+				blocks[4] = (uint8_t)i;
+				const double t0 = now_us();
+				if (!detexDecompressTextureLinear(&tex, pixels, DETEX_PIXEL_FORMAT_RGBA8)) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
+				if (i >= 0) t[i] = now_us() - t0;
+				if (i == -warm) memcpy(expect, pixels, out_bytes);
+				else if (((i + warm) & 255) == 0 && memcmp(expect, pixels, out_bytes) != 0) wrong++;
+				else if (((i + warm) & 255) == 1 && memcmp(expect, pixels, 64) == 0) wrong++;
+			}
+			qsort(t, n, sizeof t[0], cmp_double);
+			printf("latency %s%dx%d_us=%.2f p90=%.2f\n", f ? "bc7_" : "", side, side, t[n / 2], t[n * 9 / 10]);
+			free(blocks); free(pixels); free(expect);
 		}
-		qsort(t, n, sizeof t[0], cmp_double);
-		printf("latency %dx%d_us=%.2f p90=%.2f\n", side, side, t[n / 2], t[n * 9 / 10]);
-		free(blocks); free(pixels); free(expect);
 	}
 	printf("latency wrong_results=%d\n", wrong);
 	return wrong != 0;
 }
 
+/* the migration of a per-block client: the loop over a leaf function against one batched call */
+static int blocks_mode(void) {
+	static const size_t counts[3] = { 1, 1024, 1048576 };
+	int wrong = 0;
+	for (int f = 0; f < 2; f++) {
+		const uint32_t format = f ? DETEX_TEXTURE_FORMAT_BPTC : DETEX_TEXTURE_FORMAT_BC1;
+		const size_t bs = f ? 16 : 8;
+		(void)format;
+		for (int c = 0; c < 3; c++) {
+			const size_t n = counts[c];
+			uint8_t *blocks = (uint8_t *)malloc(n * bs), *loop_px = (uint8_t *)malloc(n * 64), *loop_ok = (uint8_t *)malloc(n);
+			uint64_t state = 0xB10C5 + 977 * c + f;
+			for (size_t k = 0; k < n * bs; k += 8) {		/* splitmix64 */
+				state += 0x9E3779B97F4A7C15ull;
+				uint64_t z = state;
+				z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+				memcpy(blocks + k, &z, 8);
+			}
+			double loop_us = -1.0, batched_us = -1.0;
+#ifdef WITH_DETEXHIP
+			const int do_loop = n <= 1024;			/* (a million trips to the GPU would take seconds) */
+#else
+			const int do_loop = 1;
+#endif
+			if (do_loop) {
+				for (int rep = 0; rep < 3; rep++) {		/* best of three */
+					const double t0 = now_us();
+					for (size_t i = 0; i < n; i++) {
+						loop_ok[i] = f ? detexDecompressBlockBPTC(blocks + i * bs, DETEX_MODE_MASK_ALL, 0, loop_px + i * 64)
+							: detexDecompressBlockBC1(blocks + i * bs, DETEX_MODE_MASK_ALL, 0, loop_px + i * 64);
+						if (!loop_ok[i]) memset(loop_px + i * 64, 0, 64);
+					}
+					const double dt = now_us() - t0;
+					if (loop_us < 0 || dt < loop_us) loop_us = dt;
+				}
+			}
+#ifdef WITH_DETEXHIP
+			uint8_t *px = (uint8_t *)malloc(n * 64), *ok = (uint8_t *)malloc(n);
+			for (int rep = 0; rep < 5; rep++) {
+				memset(ok, 0xA5, n);
+				const double t0 = now_us();
+				const bool all = detexhipDecompressBlocks(format, blocks, n, DETEX_MODE_MASK_ALL, 0, px, ok);
+				const double dt = now_us() - t0;
+				if (rep && (batched_us < 0 || dt < batched_us)) batched_us = dt;		/* (the first call sizes the staging buffers) */
+				int any_bad = 0;
+				for (size_t i = 0; i < n; i++) any_bad |= ok[i] != 1;
+				if (all == (any_bad != 0)) wrong++;
+			}
+			if (do_loop && (memcmp(px, loop_px, n * 64) != 0 || memcmp(ok, loop_ok, n) != 0)) wrong++;
+			free(px); free(ok);
+#endif
+			printf("blocks format=%s n=%zu loop_us=%.2f batched_us=%.2f loop_ns_per_block=%.1f batched_ns_per_block=%.1f\n", f ? "BPTC" : "BC1", n, loop_us, batched_us,
+				loop_us * 1e3 / (double)n, batched_us * 1e3 / (double)n);
+			free(blocks); free(loop_px); free(loop_ok);
+		}
+	}
+	printf("blocks wrong_results=%d\n", wrong);
+	return wrong != 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc >= 2 && !strcmp(argv[1], "--latency")) return latency();
+	if (argc >= 2 && !strcmp(argv[1], "--blocks")) return blocks_mode();
 	if (argc >= 2 && !strcmp(argv[1], "--sha256-selftest")) {
 		char hex[65];
 		sha256_of((const uint8_t *)"abc", 3, hex); printf("abc %s\n", hex);

@@ -59,6 +59,14 @@ int main() {
 	REFUSED(detexhipDecompressBlocksDevice(0, in, 1, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
 	REFUSED(detexhipDecompressBlocksDevice(BC1, in + 1, 1, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
 	REFUSED(detexhipDecompressBlocksDevice(BC1, in, (size_t)1 << 40, DETEX_MODE_MASK_ALL, 0, out, nullptr, nullptr) == 0);
+	// the batched host-pointer block entry and the ABI check
+	REFUSED(detexhipDecompressBlocks(0x14000320u, in, 4, DETEX_MODE_MASK_ALL, 0, out, nullptr));
+	REFUSED(detexhipDecompressBlocks(BC1, nullptr, 4, DETEX_MODE_MASK_ALL, 0, out, nullptr));
+	REFUSED(detexhipDecompressBlocks(BC1, in, 4, DETEX_MODE_MASK_ALL, 0, nullptr, nullptr));
+	REFUSED(detexhipDecompressBlocks(BC1, in, (size_t)1 << 40, DETEX_MODE_MASK_ALL, 0, out, nullptr));
+	if (!detexhipDecompressBlocks(BC1, nullptr, 0, DETEX_MODE_MASK_ALL, 0, nullptr, nullptr)) { printf("zero blocks must succeed\n"); g_failures++; }
+	REFUSED(detexhipCheckAbi(DETEXHIP_ABI_VERSION + 1) == 0);
+	if (detexhipCheckAbi(DETEXHIP_ABI_VERSION) != 0) { printf("the header's own ABI version was refused\n"); g_failures++; }
 	// mip levels
 	detexhipLevel lv[17];
 	for (auto &l : lv) l = detexhipLevel{ in, out, 16, 4, 4, 1, 1 };

@@ -179,6 +179,18 @@ class DetexAPI:
         ok = self.block_fn(fmt)(_ptr(data), mode_mask, flags, _ptr(out))
         return bool(ok), out
 
+    def blocks(self, fmt, data, mode_mask=0xFFFFFFFF, flags=0, want_ok=True):
+        """detexhipDecompressBlocks (libdetexhip only; include/detexhip.h): n blocks in one call -> (all_ok, ok[n] or None, pixels[n, 16*px])"""
+        f = self.lib.detexhipDecompressBlocks
+        f.argtypes = [ctypes.c_uint32, _u8p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, _u8p, _u8p]
+        f.restype = ctypes.c_bool
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        n = data.size // fmt.block_bytes
+        out = np.full((n, 16 * fmt.pixel_bytes), 0xA5, np.uint8)
+        ok = np.full(n, 0xA5, np.uint8) if want_ok else None
+        r = f(fmt.texture_format, _ptr(data), n, mode_mask, flags, _ptr(out), _ptr(ok) if want_ok else None)
+        return bool(r), ok, out
+
     def error(self):
         m = self.lib.detexGetErrorMessage()
         return None if m is None else m.decode()

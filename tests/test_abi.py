@@ -29,13 +29,17 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = binding.load()
     declared = _declared_symbols()
-    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 10 + 2) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device incl. the host-output entry, release, host aliases, half table, accumulating histogram, quirk switch, the two resident-service calls), data tables
+    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 10 + 2 + 2) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device incl. the host-output entry, release, host aliases, half table, accumulating histogram, quirk switch, the two resident-service calls; round 5: the batched host-pointer block entry, the ABI check), data tables
     out = subprocess.check_output(["nm", "-D", "--defined-only", binding.LIB_PATH], text=True)
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert declared <= exported, sorted(declared - exported)
     # nothing of the checker leaks into the product
     assert not any(s.startswith("orc_") for s in exported)
     assert lib.detexhipVersion().decode().startswith("libdetexhip")
+    # the extension ABI's version check (struct layouts of detexhip.h): the header's number is accepted, any other refused with a message
+    abi = int(re.search(r"#define DETEXHIP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "detexhip.h")).read()).group(1))
+    assert lib.detexhipCheckAbi(abi) == 0 and lib.detexhipCheckAbi(abi - 1) != 0 and "extension ABI" in binding.last_error()
+    assert ("extension ABI %d" % abi) in lib.detexhipVersion().decode()
 
 
 def test_product_does_not_link_the_oracle():

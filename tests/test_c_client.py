@@ -100,3 +100,18 @@ def test_c_client_back_to_back_small_calls(built, idle_us):
             rows.update(_parse(l)[1])
     assert rows.get("wrong_results") == "0", r.stdout
     assert all(k in rows for k in ("one_block_us", "64x64_us", "128x128_us", "256x256_us")), r.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_batched_blocks_against_the_leaf_loop(built):
+    """the migration path of a per-block client from compiled C (both headers): 1, 1024 and 1048576 independent BC1 / BC7 blocks through ONE
+    detexhipDecompressBlocks call == the loop over the leaf function block by block (pixels and ok bytes; n <= 1024), and the call's bool
+    == all(ok)"""
+    for exe in built:
+        r = subprocess.run([exe, "--blocks"], capture_output=True, text=True, env=_clean_env(), timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rows = [l for l in r.stdout.splitlines() if l.startswith("blocks format=")]
+        assert len(rows) == 6 and "blocks wrong_results=0" in r.stdout, r.stdout
+        for l in rows:
+            assert float(_parse(l)[1]["batched_us"]) > 0, l
+        print(os.path.basename(exe)); print(r.stdout)

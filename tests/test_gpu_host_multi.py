@@ -241,3 +241,71 @@ def test_multi_device_entries_from_concurrent_threads(torch_cuda, oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+# ---- the gather's three copy branches (multi_device.cpp: flat peer copy, 2-D copy over a peer mapping, row-wise copies without one) ----------
+_GATHER_WORKER = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import oracle_lib as ol
+from detex_amd import binding, formats as F
+binding.load()
+orc = ol.Oracle()
+ndev = binding.load().detexhipGetDeviceCount()
+out = {"ndev": ndev, "cases": []}
+for name, W, H, shards, pad in (("BC1", 1024, 520, 3, 0), ("BC1", 1024, 520, 3, 48), ("BPTC_FLOAT", 512, 256, 4, 64), ("RGTC1", 512, 36, 2, 7)):
+    fmt = F.BY_NAME[name]
+    px = fmt.pixel_bytes
+    unit = px if px < 4 else 4
+    pitch = W * px + (pad + unit - 1) // unit * unit
+    data = ol.stream_u(fmt, ((W + 3) // 4) * ((H + 3) // 4), seed=0x6A7 + fmt.index + pad)
+    _, want = orc.linear(fmt, data, W, H)
+    for gather in sorted({0, ndev - 1}):
+        devices = [(gather + 1 + g) %% ndev for g in range(shards)]       # with >= 2 devices the first shard is NOT on the gather device
+        r = binding.decompress_linear_multi_device(fmt, W, H, devices, host_blocks=data, gather_device=gather, pitch=pitch if pad else None)
+        img = r["gathered"].cpu().numpy().reshape(H, pitch)
+        out["cases"].append({"name": name, "pad": pad, "gather": gather, "devices": devices, "peer_access": r["peer_access"],
+                             "pixels": bool(np.array_equal(img[:, :W * px].reshape(-1), want.reshape(-1))),
+                             "canaries": bool((img[:, W * px:] == 0xA5).all())})
+print(json.dumps(out))
+'''
+
+
+def _run_gather_worker(env_extra):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GATHER_WORKER % {"root": root}], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_extra))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_gather_branch_without_peer_mapping_runs_on_any_box():
+    """DETEXHIP_PEER_ACCESS=0 (multi_device.cpp: peer_mapping_allowed): no pair is treated as mapped, so every gather copy takes the branch
+    of an unmapped pair -- flat hipMemcpyPeerAsync for dense rows, ONE hipMemcpyPeerAsync PER ROW for padded pitches -- which a one-GPU box
+    otherwise never executes (a device always 'maps' itself).  Pixels == the oracle, canaries between the rows intact, peer_access == 0"""
+    res = _run_gather_worker({"DETEXHIP_PEER_ACCESS": "0"})
+    assert len(res["cases"]) >= 4
+    for c in res["cases"]:
+        assert c["pixels"] and c["canaries"], c
+        assert all(p == 0 for p in c["peer_access"]), c
+
+
+def test_gather_across_devices_all_three_branches():
+    """gather_device != the shard's device (needs >= 2 visible GPUs): dense rows (flat peer copy), padded rows over a peer mapping (2-D copy)
+    and -- in the test above -- padded rows without one.  On a one-GPU box this is SKIPPED, and says so: the cross-device copies of
+    multi_device.cpp have then only run with source and destination on the same device"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        reason = ("only %d GPU visible: the cross-device gather copies (hipMemcpyPeerAsync / hipMemcpy2DAsync between two devices) cannot execute here; "
+                  "same-device and no-mapping branches are covered by the tests above" % torch.cuda.device_count())
+        print("SKIPPED:", reason)
+        pytest.skip(reason)
+    res = _run_gather_worker({})
+    crossed = 0
+    for c in res["cases"]:
+        assert c["pixels"] and c["canaries"], c
+        crossed += sum(1 for d in c["devices"] if d != c["gather"])
+        assert all(p in (0, 1) for p in c["peer_access"]), c
+    assert crossed > 0
+    print("peer_access per case:", [(c["name"], c["pad"], c["gather"], c["peer_access"]) for c in res["cases"]])

@@ -114,6 +114,55 @@ def test_leaf_functions_host_api(fmt, hiplib, forced_vectors):
     assert r and np.array_equal(out, want[good])
 
 
+# ---- the batched HOST-pointer block entry (detexhipDecompressBlocks): the loop over a leaf function as one call ------------------
+@pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
+def test_batched_host_blocks_mask_flag_matrix(fmt, hiplib, forced_vectors, golden_json, oracle):
+    """all forced vectors of the format (every mode and invalid class) through detexhipDecompressBlocks under every (mode_mask, flags)
+    pair of the matrix: pixels (sha256) and per-block ok bits == the compiled reference's leaf function, the bool result == all(ok),
+    the reference's error text on failure"""
+    blocks = forced_vectors[fmt.name + "/in"]
+    n = len(blocks)
+    golden = golden_json("maskflags.json")[fmt.name]
+    for mask, flags in streams.MASK_FLAG_MATRIX:
+        r, ok, out = hiplib.blocks(fmt, blocks, mask, flags)
+        g = golden["%08X/%X" % (mask, flags)]
+        want_ok = np.unpackbits(np.frombuffer(bytes.fromhex(g["ok_bits"]), np.uint8))[:n]
+        assert np.array_equal(ok, want_ok), (fmt.name, hex(mask), flags)
+        assert r == bool(want_ok.all())
+        if not r:
+            assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+        if sha(out) != g["sha256"]:
+            ok_o, out_o = oracle.blocks(fmt, blocks, mask, flags)
+            raise AssertionError("%s mask %08X flags %X: %s" % (fmt.name, mask, flags, _first_diff(out, out_o, out.shape[1])))
+
+
+@pytest.mark.parametrize("name", ["BC1", "RGTC1", "BPTC", "BPTC_FLOAT", "ETC2_EAC", "EAC_SIGNED_R11"])
+def test_batched_host_blocks_sizes(name, hiplib, oracle):
+    """batch sizes on both sides of every internal boundary (one block: the leaf path; up to the pinned exchange's limit; staged through
+    device buffers above it; ragged tails; a misaligned input pointer; no ok array): == the oracle's per-block decode"""
+    fmt = F.BY_NAME[name]
+    per = fmt.block_bytes + 16 * fmt.pixel_bytes + 1
+    edge = (1280 << 10) // per
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000, edge - 1, edge, edge + 1, edge + 300, 70001):
+        data = ol.stream_u(fmt, n, seed=0xBA7C + n)
+        want_ok, want = oracle.blocks(fmt, data)
+        r, ok, out = hiplib.blocks(fmt, data)
+        assert np.array_equal(ok.astype(bool), want_ok), (name, n)
+        assert np.array_equal(out, want), (name, n, _first_diff(out, want, want.shape[1]))
+        assert r == bool(want_ok.all())
+    # unaligned input, no ok array
+    n = 777
+    raw = np.zeros(n * fmt.block_bytes + 1, np.uint8)
+    raw[1:] = ol.stream_u(fmt, n, seed=0x0DD)
+    want_ok, want = oracle.blocks(fmt, raw[1:])
+    r, ok, out = hiplib.blocks(fmt, raw[1:], want_ok=False)
+    assert ok is None and np.array_equal(out, want) and r == bool(want_ok.all())
+    # zero blocks: true, nothing touched; an unknown format: false + message
+    f = hiplib.lib.detexhipDecompressBlocks
+    assert f(fmt.texture_format, None, 0, 0xFFFFFFFF, 0, None, None)
+    assert not f(0x14800334, ol._ptr(raw), 1, 0xFFFFFFFF, 0, ol._ptr(raw), None) and "not a block-compressed format" in hiplib.error()
+
+
 # ---- (iii) clipped sizes through the host API and the device API with a padded pitch -------------
 @pytest.mark.parametrize("fmt", F.FORMATS, ids=FMT_IDS)
 def test_clipped_sizes(fmt, hiplib, torch_cuda, forced_vectors, clip_vectors):

@@ -235,3 +235,28 @@ def test_release_with_a_resident_kernel_running(resident, torch_cuda, oracle):
         lib.lib.detexhipReleaseThreadResources.restype = None
         lib.lib.detexhipReleaseThreadResources()
     torch_cuda.cuda.synchronize()
+
+
+def test_multi_tile_requests_with_changing_payloads(resident, oracle):
+    """requests for more than one tile (the leader hands them to the other workgroups through device memory) back to back, each with
+    ANOTHER geometry / layout than the one before -- 2, 3 and 4 tiles, clipped and whole, linear and block-major: every workgroup
+    acknowledges every such request before `done` is published (kernels_resident.h: resident_acknowledge), so no follower can pair a
+    stale request number with a newer payload; 600 calls, each == the oracle"""
+    lib = resident
+    fmt = F.BY_NAME["BC3"]
+    shapes = [(128, 128, False), (96, 64, False), (125, 90, False), (128, 64, True), (68, 68, False), (112, 96, True), (128, 124, False)]
+    cases = []
+    for k, (w, h, tiled) in enumerate(shapes):
+        wb, hb = (w + 3) // 4, (h + 3) // 4
+        assert 256 < wb * hb <= 1024
+        data = ol.stream_u(fmt, wb * hb, seed=0x7117 + k)
+        want = oracle.tiled(fmt, data, wb, hb) if tiled else oracle.linear(fmt, data, w, h)
+        cases.append((w, h, wb, hb, tiled, data, want))
+    served0, _ = _stats(lib.lib)
+    rng = np.random.default_rng(5)
+    for k in range(600):
+        w, h, wb, hb, tiled, data, (want_ok, want) = cases[int(rng.integers(len(cases)))]
+        ok, got = lib.tiled(fmt, data, wb, hb) if tiled else lib.linear(fmt, data, w, h)
+        assert ok == want_ok and np.array_equal(got, want), (k, w, h, tiled)
+    served1, _ = _stats(lib.lib)
+    assert served1 - served0 >= 590
