@@ -22,7 +22,8 @@ struct ThreadContext {
 	hipStream_t stream = nullptr;
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
-	uint32_t *d_status = nullptr;	// [0] status word, [0..15] histogram bins, [16] the workgroup counter of the small calls' completion (Completion::counter)
+	uint32_t *d_status = nullptr;	// 32 words: [0] status word, [0..15] histogram bins, [16..19] workgroup counters of the small calls' completions (Completion::counter),
+					// [24] the status word of the staged texture path, which is ZERO between calls (kStagedStatusWord)
 	uint32_t ticket = 0;		// last completion ticket handed out (never 0: the completion word starts as 0)
 	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
 	uint8_t *h_pin = nullptr, *d_pin = nullptr;
@@ -139,8 +140,11 @@ constexpr size_t kDoneOffset = 8;		// the completion word inside the exchange bu
 uint32_t next_ticket(ThreadContext &c) { if (++c.ticket == 0u) c.ticket = 1u; return c.ticket; }
 // Spins on the completion word the kernel just launched on c.stream releases.  Every 2^14 polls (a few hundred microseconds) the
 // stream is asked whether it failed or finished without the word (a kernel that faulted never publishes): no unbounded wait.
-bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket) {
-	const uint32_t *word = reinterpret_cast<const uint32_t *>(x.h_base + kDoneOffset);
+constexpr int kStagedStatusWord = 24;		// ThreadContext::d_status
+constexpr size_t kBandDoneOffset = 64;		// ... and of band k of a banded call: kBandDoneOffset + 16 * k (k < kDirectBands)
+constexpr int kDirectBands = 4;
+bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket, size_t word_offset = kDoneOffset) {
+	const uint32_t *word = reinterpret_cast<const uint32_t *>(x.h_base + word_offset);
 	for (uint32_t polls = 1;; polls++) {
 		if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == ticket) return true;
 		cpu_relax();
@@ -201,6 +205,25 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 namespace detexhip {
 void release_thread_context() { t_ctx.release(); }
 }
+
+// After ~0.3 s without work an MI355X sits at its idle shader clock (94 MHz in the amdgpu hwmon file) and the FIRST kernel of any kind
+// pays the way back up: 125-157 us for an 8192^2 BC1 decode that takes 43 us at steady state, 125 us for a plain fill of the same image,
+// 99 us for a 64x64 decode that otherwise takes 5 (profiles/r05/cold_trace_*.json) -- device state, not this library's code or data.
+// A client that knows a decode is coming (it is about to read the file) can start that ramp early: one empty wavefront on the
+// thread's stream, not waited for.  detexLoadKTXFile does it for threads that have decoded before.
+extern "C" void detexhipWakeDevice(void) {
+	if (!context_ready()) return;
+	ThreadContext &c = t_ctx;
+	DeviceScope scope(c.device);
+	if (scope.ok) { (void)launch_wake(c.stream); (void)hipGetLastError(); }
+}
+namespace detexhip {
+void wake_device_if_in_use() {
+	if (!t_ctx.ready) return;		// (no context yet: the first decode pays its creation, milliseconds, whatever the clocks do)
+	DeviceScope scope(t_ctx.device);
+	if (scope.ok) { (void)launch_wake(t_ctx.stream); (void)hipGetLastError(); }
+}
+}  // namespace detexhip
 
 extern "C" void detexhipGetResidentStats(unsigned long long *requests, unsigned long long *instances) {
 	if (requests) *requests = t_ctx.service.served;
@@ -307,6 +330,12 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
 		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
 	};
+	auto copy_out_rows = [&](const uint8_t *res, size_t y0, size_t y1) {		// linear layout: image rows [y0, y1)
+		if (y1 > cov_h) y1 = cov_h;
+		if (y0 >= y1) return;
+		if (cov_w == width) memcpy(pixel_buffer + y0 * width * px, res + y0 * width * px, (y1 - y0) * width * px);
+		else for (size_t y = y0; y < y1; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+	};
 	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
 		// the smallest textures (either layout), from the second call in a row on: a request to the resident kernel instead of a launch
 		if (wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {
@@ -345,17 +374,44 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 			// the one-level form of the mip-chain kernel (any geometry in one launch), which publishes the completion word
 			const int epi = prepared_epilogue(texture->format, pixel_format);
 			if (epi == -2) return false;
-			const uint32_t ticket = next_ticket(c);
-			LevelsArgs a{};
-			a.status = d_st; a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
-			a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket };
-			a.table.n_levels = 1;
-			LevelDesc &lv = a.table.level[0];
-			lv.blocks = x.d_base + x.in_off; lv.pixels = x.d_base + x.out_off; lv.pitch = width * px;
-			lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * hb); lv.width = (uint32_t)width; lv.height = (uint32_t)height;
-			a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
-			HIP_TRY(f->levels(a), "kernel launch");
-			if (!wait_for_ticket(c, x, ticket)) return false;
+			// Above a quarter MiB of pixels the call is made in kDirectBands bands of block rows (a band is one contiguous range of blocks
+			// and of image rows, texture.c:115-141), one launch and one completion word each, all launched at once: the caller copies band
+			// k out of the pinned buffer while the kernels of the later bands are still writing theirs across the link -- the copy-out of
+			// freshly written pinned memory runs at ~20 GB/s on one host thread, half the link's rate, and was a third of a 512x512 call.
+			const int bands = (out_bytes > ((size_t)256 << 10) && hb >= (size_t)(2 * kDirectBands)) ? kDirectBands : 1;
+			uint32_t tickets[kDirectBands];
+			size_t band_y1[kDirectBands];
+			for (int b = 0; b < bands; b++) {
+				const size_t r0 = (size_t)b * hb / (size_t)bands, r1 = (size_t)(b + 1) * hb / (size_t)bands;
+				const size_t y0 = r0 * 4u < height ? r0 * 4u : height, y1 = r1 * 4u < height ? r1 * 4u : height;
+				band_y1[b] = b + 1 == bands ? height : y1;
+				tickets[b] = next_ticket(c);
+				LevelsArgs a{};
+				a.status = d_st; a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
+				a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + (bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)), c.d_status + 16 + b, tickets[b] };
+				a.table.n_levels = 1;
+				LevelDesc &lv = a.table.level[0];
+				lv.blocks = x.d_base + x.in_off + r0 * wb * bs; lv.pixels = x.d_base + x.out_off + y0 * width * px; lv.pitch = width * px;
+				lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * (r1 - r0)); lv.width = (uint32_t)width; lv.height = (uint32_t)(y1 - y0);
+				a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
+				if (lv.n_blocks == 0 || y1 == y0) { tickets[b] = 0; continue; }		// (rows of blocks below the image: nothing to decode)
+				HIP_TRY(f->levels(a), "kernel launch");
+			}
+			if (bands == 1) {
+				if (!wait_for_ticket(c, x, tickets[0])) return false;
+			} else {
+				size_t y_done = 0;
+				for (int b = 0; b < bands; b++) {
+					if (tickets[b] != 0 && !wait_for_ticket(c, x, tickets[b], kBandDoneOffset + 16u * (size_t)b)) return false;
+					copy_out_rows(x.h_base + x.out_off, y_done, band_y1[b]);
+					y_done = band_y1[b];
+				}
+				if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
+					detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+					return false;
+				}
+				return true;
+			}
 		}
 		copy_out(x.h_base + x.out_off);
 		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
@@ -364,26 +420,47 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		}
 		return true;
 	}
-	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, out_bytes)) return false;
-	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
-	uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);
-	uint32_t status = 0;
-	HIP_TRY(hipMemcpyAsync(d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+	// Larger textures: staged through device memory.  Per call (measured piece by piece, tools/ubench/host_midsize.hip): the status word
+	// is NOT zeroed by a memset (it is zero between calls: a call that raised it zeroes it again afterwards), it comes back into a PINNED
+	// word (a 4-byte copy into pageable memory costs 25 us, into pinned memory 13), and blocks of up to Tune::kHostPinnedInputBytes reach
+	// the kernel through the pinned buffer, read across the link as it decodes (a memcpy of 512 KiB: 4 us; the runtime's copy out of
+	// pageable memory: 27).  The pixels travel by the runtime's device-to-host copy into the caller's pageable buffer: at these sizes it
+	// pins the pages and runs at the link's rate, which no copy loop of one host thread reaches.
+	const bool pinned_in = in_bytes <= Tune::kHostPinnedInputBytes;
+	DirectExchange x;
+	if (!direct_exchange(c, pinned_in ? in_bytes : 0, 0, &x)) return false;
+	if (!reserve(&c.d_out, &c.out_cap, out_bytes) || (!pinned_in && !reserve(&c.d_in, &c.in_cap, in_bytes))) return false;
+	uint8_t *d_out = static_cast<uint8_t *>(c.d_out);
+	const uint8_t *d_in;
+	if (pinned_in) {
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		d_in = x.d_base + x.in_off;
+	} else {
+		HIP_TRY(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
+		d_in = static_cast<const uint8_t *>(c.d_in);
+	}
+	uint32_t *d_status = c.d_status + kStagedStatusWord;
+	volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
+	*h_status = 0xFFFFFFFFu;
 	int rc;
 	if (tiled)
-		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, c.d_status);
+		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status);
 	else
 		rc = detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format,
-			c.stream, c.d_status);
+			c.stream, d_status);
 	if (rc != 0) return false;
 	if (tiled || (cov_w == width && cov_h == height)) {
 		HIP_TRY(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	} else if (cov_w > 0 && cov_h > 0) {
 		HIP_TRY(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)");
 	}
-	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	const uint32_t status = *h_status;
 	if (status != 0) {
+		// (the word is zero between calls: restore that before reporting)
+		HIP_TRY(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync");
+		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 		// same text the reference leaves behind after a failed block (texture.c:63-64)
 		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
 		return false;

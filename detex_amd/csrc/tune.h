@@ -45,6 +45,9 @@ struct ProductTune {
 	// host-pointer tier: textures whose blocks + pixels fit in this many bytes are exchanged through pinned host memory the
 	// kernel reads and writes directly (one launch + one synchronisation; host_tier.cpp: direct_exchange)
 	static constexpr unsigned long kHostDirectBytes = 1280u << 10;	// up to 512 x 512 RGBA8 (measured: 64^2 51 -> 18 us, 256^2 83 -> 31 us per call)
+	// ... and larger textures whose BLOCKS fit in this many bytes hand them over through the same pinned buffer (read by the kernel across
+	// the link) instead of an upload out of pageable memory; 0 = always upload
+	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };

@@ -14,8 +14,11 @@ OUT = os.path.join(ROOT, "gpurun_out", "rccl_preflight")
 pytestmark = pytest.mark.gpu
 
 
-def _env(port, **extra):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,ENV")
+def _env(port, log="rccl", **extra):
+    # (RCCL prints its INFO lines to STDOUT unless told otherwise: NCCL_DEBUG_FILE keeps the JSON line of the worker / of bench.py clean)
+    os.makedirs(OUT, exist_ok=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,ENV",
+               NCCL_DEBUG_FILE=os.path.join(OUT, log + "_%p.log"))
     env.update(extra)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -34,8 +37,8 @@ def test_sharding_gathers_under_rccl_world_size_1():
     backend nccl: every gathered image == the oracle"""
     os.makedirs(OUT, exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_preflight_worker.py")], capture_output=True, text=True, timeout=600,
-                       env=_env(29533 + os.getpid() % 200))
-    open(os.path.join(OUT, "sharding_worker_rccl.log"), "w").write(r.stderr[-200000:] + "\n--- stdout\n" + r.stdout)
+                       env=_env(29533 + os.getpid() % 200, log="rccl_sharding_worker"))
+    open(os.path.join(OUT, "sharding_worker.out"), "w").write(r.stderr[-20000:] + "\n--- stdout\n" + r.stdout)
     assert r.returncode == 0, r.stderr[-3000:]
     res = _last_json(r.stdout)
     assert res["backend"] == "nccl" and res["ok"], res
@@ -49,8 +52,8 @@ def test_bench_multi_gpu_branch_under_rccl_world_size_1():
     gathers (timed), BASELINE configs[4] (BC6H 32768^2: 8 GiB of pixels) with its digests and gathers, the weak line"""
     os.makedirs(OUT, exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu"], capture_output=True, text=True,
-                       timeout=1200, env=_env(29733 + os.getpid() % 200, DETEX_BENCH_FORCE_DIST="1"), cwd=ROOT)
-    open(os.path.join(OUT, "bench_forced_dist_rccl.log"), "w").write(r.stderr[-200000:])
+                       timeout=1200, env=_env(29733 + os.getpid() % 200, log="rccl_bench_forced_dist", DETEX_BENCH_FORCE_DIST="1"), cwd=ROOT)
+    open(os.path.join(OUT, "bench_forced_dist.err"), "w").write(r.stderr[-20000:])
     open(os.path.join(OUT, "bench_forced_dist.json"), "w").write(r.stdout)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
@@ -75,7 +78,7 @@ def test_scale_preflight_script_ends_cleanly_without_enough_gpus():
     import torch
     n = 2
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_preflight.sh"), str(n)], capture_output=True, text=True, timeout=1500,
-                       env=dict(_env(0), STEPS="3", WARMUP="1", PORT=str(29911 + os.getpid() % 50)), cwd=ROOT)
+                       env=dict(_env(0, log="rccl_scale_script"), STEPS="3", WARMUP="1", PORT=str(29911 + os.getpid() % 50)), cwd=ROOT)
     print(r.stdout[-1500:])
     if torch.cuda.device_count() < n:
         assert r.returncode == 5, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -10,6 +10,8 @@ the launch stream) while a thread samples the shader clock and board power from 
    tiny_first      a 64x64 decode of the same format first (loads the same kernel code, touches the same tables), then the 20 launches
                    -> separates instruction-cache / table warm-up (which it would fix) from the device state (which it would not)
    other_buffers   the 20 launches write a buffer that was never touched before (fresh allocation): page-table / TLB warm-up of the output
+   wake_then_work  detexhipWakeDevice() (one empty wavefront, not waited for), 200 us of host work (the file read a client does before it
+                   decodes), then the 20 launches: what the mitigation buys a client whose decode is a file read away
    spin_wait       no idle at all between measurement blocks (control)
 Prints one JSON object; profiles/r05/cold_trace.json is a copy."""
 import json
@@ -92,6 +94,12 @@ def main():
     def fill_once():
         assert fill_lib.hbmref_fill_image(fill_buf.data_ptr(), side * fmt.pixel_bytes, side, 0, 2, 7, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
 
+    lib = binding.load()
+    lib.detexhipWakeDevice.restype = None
+    api = ol.DetexAPI(binding.LIB_PATH)
+    api.block(fmt, ol.stream_u(fmt, 1))          # (the host tier's context of this thread exists: detexhipWakeDevice launches on its stream)
+    wake = lib.detexhipWakeDevice
+
     def timed(fn, n):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         ev[0].record()
@@ -109,7 +117,7 @@ def main():
     res = {"format": name, "side": side, "steady_us_median": sorted(steady)[100], "scenarios": {}}
     row_bytes = side * fmt.pixel_bytes
     for idle in (0.3, 3.0):
-        for scen in ("decode", "fill_first", "tiny_first", "other_buffers", "spin_wait"):
+        for scen in ("decode", "fill_first", "tiny_first", "other_buffers", "wake_then_work", "spin_wait"):
             if scen == "spin_wait" and idle != 0.3:
                 continue
             for _ in range(300):
@@ -123,6 +131,12 @@ def main():
             with Sampler() as smp:
                 if scen == "fill_first":
                     row["fill_first_launch_us"] = timed(fill_once, 1)[0]                    # ONE launch of the reference fill into its own (pre-allocated) image
+                elif scen == "wake_then_work":
+                    t0 = time.perf_counter()
+                    wake()
+                    row["wake_call_us"] = round((time.perf_counter() - t0) * 1e6, 1)
+                    while time.perf_counter() - t0 < 200e-6:
+                        pass
                 elif scen == "tiny_first":
                     row["tiny_first_launch_us"] = timed(lambda: binding.decompress_linear_device(fmt, small, 64, 64, out=small_out, status=status), 1)[0]
                 row["decode_us"] = timed((lambda: decode(fresh)) if fresh is not None else decode, 20)

@@ -14,6 +14,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0 NCCL_DEBUG=${NCCL_DEBUG:-INFO} NCCL_DEBUG_SU
 NS=${*:-2 4 8}
 for N in $NS; do
   echo "== N=$N"
+  export NCCL_DEBUG_FILE=$PWD/$OUT/rccl_n${N}_%p.log       # (RCCL's INFO lines would otherwise go to stdout, into the JSON line's file)
   if [ "$N" = 1 ]; then
     DETEX_BENCH_FORCE_DIST=1 MASTER_PORT=$PORT timeout 900 python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --no-cpu > $OUT/bench_n1_forced.json 2> $OUT/rccl_n1.log
     rc=$?
@@ -24,7 +25,7 @@ for N in $NS; do
   fi
   f=$OUT/bench_n$N.json; [ "$N" = 1 ] && f=$OUT/bench_n1_forced.json
   echo "exit code $rc"; grep -m3 "NOT one rank per GPU" $OUT/rccl_n$N.log | cut -c1-300; tail -1 $f | cut -c1-400
-  grep -m1 -i "NCCL version\|RCCL version" $OUT/rccl_n$N.log
+  cat $OUT/rccl_n${N}_*.log 2>/dev/null | grep -m1 -i "NCCL version\|RCCL version"
   # (torch.distributed.run reports a failed worker with its own exit code 1: bench.py's code 5 is recognised by its message)
   if [ $rc -ne 0 ] && grep -q "NOT one rank per GPU" $OUT/rccl_n$N.log; then echo "stopping: this box has fewer than $N GPUs (bench.py exit code 5, no RCCL call was made)"; exit 5; fi
   if [ $rc -ne 0 ]; then echo "stopping: N=$N ended with exit code $rc"; tail -5 $OUT/rccl_n$N.log | cut -c1-300; exit $rc; fi

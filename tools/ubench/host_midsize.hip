@@ -88,6 +88,20 @@ int main(int argc, char **argv) {
 		const double d2h4_pinned = median_us(200, [&] { CK(hipMemcpyAsync(p_words + 64, d_words, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); });
 		printf("{\"primitives_us\": {\"empty_launch_sync\": %.2f, \"memsetAsync4_sync\": %.2f, \"d2h_4B_to_stack_sync\": %.2f, \"d2h_4B_to_pinned_sync\": %.2f}}\n", launch_sync, memset_sync, d2h4_stack, d2h4_pinned);
 	}
+	{	// the runtime's copies out of / into PAGEABLE memory against size: where does it switch from staging to pinning the caller's pages?
+		printf("{\"pageable_copy_curve_us\": {");
+		bool first = true;
+		for (size_t kib : { 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192 }) {
+			const size_t n = kib << 10;
+			if (n > OUT_MAX || n > IN_MAX * 8) break;
+			const double d = median_us(30, [&] { CK(hipMemcpyAsync(h_out, d_out, n, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); });
+			const double u = n <= IN_MAX ? median_us(30, [&] { CK(hipMemcpyAsync(d_in, h_in, n, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }) : -1.0;
+			const double dp = median_us(30, [&] { CK(hipMemcpyAsync(p_out, d_out, n, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); });
+			printf("%s\"%zuKiB\": {\"d2h\": %.1f, \"h2d\": %.1f, \"d2h_pinned\": %.1f}", first ? "" : ", ", kib, d, u, dp);
+			first = false;
+		}
+		printf("}}\n");
+	}
 	for (int side = 256; side <= max_side; side *= 2) {
 		const size_t out_bytes = (size_t)side * side * 4, in_bytes = out_bytes / 8;
 		const uint32_t n = (uint32_t)(in_bytes / 8), grid = (n + 255u) / 256u;
