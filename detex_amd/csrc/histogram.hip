@@ -116,13 +116,6 @@ template <int CLASS, int DWORDS> static hipError_t launch_histogram(const void *
 	return hipGetLastError();
 }
 
-// ---- detexhipWakeDevice: one empty wavefront, to start the device's way out of its idle state (host_tier.cpp has the measurements) ----------
-__global__ void wake_kernel() {}
-hipError_t launch_wake(hipStream_t stream) {
-	hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, stream);
-	return hipGetLastError();
-}
-
 hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first) {
 	switch (histogram_class) {		// (a class fixes the block size, except "no modes")
 	case kClassS3TC: return launch_histogram<kClassS3TC, 2>(blocks, n, hist, stream, zero_first);

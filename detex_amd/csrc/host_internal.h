@@ -97,8 +97,6 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant);
 
 // ---- 8f-4 (histogram.hip) ----------------------------------------------------------------------------------------------------------
-hipError_t launch_wake(hipStream_t stream);				// one empty wavefront (detexhipWakeDevice)
-void wake_device_if_in_use();						// host_tier.cpp: the same, only if the calling thread has decoded before (ktx_loader.cpp)
 hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first);
 
 // ---- resident service of the host tier's smallest calls (host_resident.cpp; protocol: path_types.h ResidentMail) ---------------------

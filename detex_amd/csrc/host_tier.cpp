@@ -206,25 +206,6 @@ namespace detexhip {
 void release_thread_context() { t_ctx.release(); }
 }
 
-// After ~0.3 s without work an MI355X sits at its idle shader clock (94 MHz in the amdgpu hwmon file) and the FIRST kernel of any kind
-// pays the way back up: 125-157 us for an 8192^2 BC1 decode that takes 43 us at steady state, 125 us for a plain fill of the same image,
-// 99 us for a 64x64 decode that otherwise takes 5 (profiles/r05/cold_trace_*.json) -- device state, not this library's code or data.
-// A client that knows a decode is coming (it is about to read the file) can start that ramp early: one empty wavefront on the
-// thread's stream, not waited for.  detexLoadKTXFile does it for threads that have decoded before.
-extern "C" void detexhipWakeDevice(void) {
-	if (!context_ready()) return;
-	ThreadContext &c = t_ctx;
-	DeviceScope scope(c.device);
-	if (scope.ok) { (void)launch_wake(c.stream); (void)hipGetLastError(); }
-}
-namespace detexhip {
-void wake_device_if_in_use() {
-	if (!t_ctx.ready) return;		// (no context yet: the first decode pays its creation, milliseconds, whatever the clocks do)
-	DeviceScope scope(t_ctx.device);
-	if (scope.ok) { (void)launch_wake(t_ctx.stream); (void)hipGetLastError(); }
-}
-}  // namespace detexhip
-
 extern "C" void detexhipGetResidentStats(unsigned long long *requests, unsigned long long *instances) {
 	if (requests) *requests = t_ctx.service.served;
 	if (instances) *instances = t_ctx.service.started;
@@ -421,8 +402,9 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		return true;
 	}
 	// Larger textures: staged through device memory.  Per call (measured piece by piece, tools/ubench/host_midsize.hip): the status word
-	// is NOT zeroed by a memset (it is zero between calls: a call that raised it zeroes it again afterwards), it comes back into a PINNED
-	// word (a 4-byte copy into pageable memory costs 25 us, into pinned memory 13), and blocks of up to Tune::kHostPinnedInputBytes reach
+	// is NOT zeroed by a memset (the device word is zero between calls: a call that raised it zeroes it again afterwards), it is read from
+	// PINNED memory (a 4-byte copy into pageable memory costs 25 us, into pinned memory 13, none at all for up to 2^20 blocks: below), and
+	// blocks of up to Tune::kHostPinnedInputBytes reach
 	// the kernel through the pinned buffer, read across the link as it decodes (a memcpy of 512 KiB: 4 us; the runtime's copy out of
 	// pageable memory: 27).  The pixels travel by the runtime's device-to-host copy into the caller's pageable buffer: at these sizes it
 	// pins the pages and runs at the link's rate, which no copy loop of one host thread reaches.
@@ -439,9 +421,13 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		HIP_TRY(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
 		d_in = static_cast<const uint8_t *>(c.d_in);
 	}
-	uint32_t *d_status = c.d_status + kStagedStatusWord;
+	// The status word: up to 2^20 blocks it lives in the pinned header itself -- only a wave that holds a failed block touches it (one
+	// load, at most one store across the link), and the call saves the copy that would fetch it (13 us); beyond that (tens of thousands
+	// of waves may hold a failed block of a random stream) it stays in device memory and is fetched into the pinned word.
+	const bool pinned_status = wb * hb <= ((size_t)1 << 20);
 	volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
-	*h_status = 0xFFFFFFFFu;
+	uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
+	*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
 	int rc;
 	if (tiled)
 		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status);
@@ -454,13 +440,14 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	} else if (cov_w > 0 && cov_h > 0) {
 		HIP_TRY(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)");
 	}
-	HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	if (!pinned_status) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
 	const uint32_t status = *h_status;
 	if (status != 0) {
-		// (the word is zero between calls: restore that before reporting)
-		HIP_TRY(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync");
-		HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		if (!pinned_status) {		// (the device word is zero between calls: restore that before reporting)
+			HIP_TRY(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync");
+			HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+		}
 		// same text the reference leaves behind after a failed block (texture.c:63-64)
 		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
 		return false;

@@ -14,7 +14,6 @@
 
 #define DETEXHIP_BUILDING_LIBRARY 1
 #include "../../include/detex.h"
-namespace detexhip { void wake_device_if_in_use(); }		// host_tier.cpp
 
 namespace {
 
@@ -47,8 +46,6 @@ void free_levels(detexTexture **textures, int n) {
 // ktx.c:36-176
 extern "C" bool detexLoadKTXFileWithMipmaps(const char *filename, int max_mipmaps, detexTexture ***textures_out,
 		int *nu_levels_out) {
-	// (the reference's sequence is load, then decode -- validate.c:135,208: an idle GPU starts its clock ramp while the file is read)
-	detexhip::wake_device_if_in_use();
 	FILE *f = fopen(filename, "rb");
 	if (!f) { detexSetErrorMessage("detexLoadKTXFileWithMipmaps: Could not open file %s", filename); return false; }
 	uint32_t header[16];

@@ -36,11 +36,6 @@ extern "C" {
 DETEXHIP_API int detexhipGetDeviceCount(void);
 DETEXHIP_API int detexhipSetDevice(int device);
 DETEXHIP_API void detexhipReleaseThreadResources(void);
-/* Starts the device's way out of its idle state without waiting for it: after ~0.3 s without work the GPU sits at its idle clock and
- * the first kernel of any kind pays 100-150 us for the ramp.  Call it when a decode is a file read away; costs one
- * asynchronous launch of an empty wavefront on the calling thread's host-tier stream.  detexLoadKTXFile does it by itself for threads that
- * have decoded before. */
-DETEXHIP_API void detexhipWakeDevice(void);
 DETEXHIP_API const char *detexhipVersion(void);
 /* The extension API's structs grow now and then (detexhipShard gained `peer_access` in 0.3 -> ABI 4): a client passes the
  * DETEXHIP_ABI_VERSION it was COMPILED with and gets 0 if this library lays the structs out the same way, non-zero (and an error

@@ -309,3 +309,24 @@ def test_gather_across_devices_all_three_branches():
         assert all(p in (0, 1) for p in c["peer_access"]), c
     assert crossed > 0
     print("peer_access per case:", [(c["name"], c["pad"], c["gather"], c["peer_access"]) for c in res["cases"]])
+
+
+@pytest.mark.parametrize("W,H", [(1024, 1024), (4100, 4096), (512, 512)])
+def test_host_tier_status_does_not_leak_between_calls(W, H, hiplib, oracle):
+    """a texture with invalid blocks (result false) followed by a valid one of the same size (result true) and again an invalid one, on
+    the pinned-exchange path (512^2), the staged path with its status word in pinned memory (1024^2) and with the device word that is
+    kept zero between calls (> 2^20 blocks): the status of one call never shows in the next"""
+    fmt = F.BY_NAME["BPTC"]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    bad = ol.stream_u(fmt, wb * hb, seed=0x57A7)                 # random BC7: 0.4 % reserved blocks
+    good = bad.copy().reshape(-1, 16)
+    good[:, 0] |= 1                                             # every block mode 0: valid
+    good = good.reshape(-1)
+    rows = min(hb, 16)
+    for k, (data, want_ok) in enumerate([(bad, False), (good, True), (bad, False), (good, True), (good, True)]):
+        ok, got = hiplib.linear(fmt, data, W, H)
+        assert ok == want_ok, (W, H, k)
+        _, ref_rows = oracle.linear(fmt, data[:rows * wb * 16], W, min(rows * 4, H))
+        assert np.array_equal(got[:ref_rows.size], ref_rows), (W, H, k)
+        if not ok:
+            assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format

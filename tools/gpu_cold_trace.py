@@ -10,8 +10,11 @@ the launch stream) while a thread samples the shader clock and board power from 
    tiny_first      a 64x64 decode of the same format first (loads the same kernel code, touches the same tables), then the 20 launches
                    -> separates instruction-cache / table warm-up (which it would fix) from the device state (which it would not)
    other_buffers   the 20 launches write a buffer that was never touched before (fresh allocation): page-table / TLB warm-up of the output
-   wake_then_work  detexhipWakeDevice() (one empty wavefront, not waited for), 200 us of host work (the file read a client does before it
-                   decodes), then the 20 launches: what the mitigation buys a client whose decode is a file read away
+   wake_then_work  one tiny kernel (not waited for), 200 us of host work (the file read a client does before it decodes), then the 20
+                   launches: can the wake-up be paid EARLY, hidden behind host work?  (Round 5 measured this with a library entry made for
+                   the purpose, detexhipWakeDevice: the call itself took 78-780 us and the decode 200 us later still paid 92-146 us for its
+                   first launch -- the device is back in its gated state within ~200 us -- so the entry was not kept:
+                   profiles/r05/cold_trace_bc1_with_wake_call.json)
    spin_wait       no idle at all between measurement blocks (control)
 Prints one JSON object; profiles/r05/cold_trace.json is a copy."""
 import json
@@ -94,11 +97,7 @@ def main():
     def fill_once():
         assert fill_lib.hbmref_fill_image(fill_buf.data_ptr(), side * fmt.pixel_bytes, side, 0, 2, 7, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
 
-    lib = binding.load()
-    lib.detexhipWakeDevice.restype = None
-    api = ol.DetexAPI(binding.LIB_PATH)
-    api.block(fmt, ol.stream_u(fmt, 1))          # (the host tier's context of this thread exists: detexhipWakeDevice launches on its stream)
-    wake = lib.detexhipWakeDevice
+    wake = status.zero_                          # (one tiny kernel on torch's stream)
 
     def timed(fn, n):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
