@@ -851,6 +851,23 @@ def main():
                     if cc:
                         cc["note"] = "the same program linked against the compiled reference (oracle/_ref), one host thread"
                         small["reference_compiled_c_client"] = cc
+                # the migration path of a per-block client: n independent blocks through ONE detexhipDecompressBlocks call against the loop over the
+                # leaf function, in this library and in the compiled reference (tests/c_client/detex_client --blocks)
+                def client_blocks(path):
+                    r = subprocess.run([path, "--blocks"], capture_output=True, text=True, timeout=180)
+                    rows = {}
+                    for line in r.stdout.splitlines():
+                        if line.startswith("blocks format="):
+                            f = dict(kv.split("=") for kv in line.split()[1:])
+                            rows["%s/%s" % (f["format"], f["n"])] = {k: (None if float(f[k]) < 0 else round(float(f[k]), 2)) for k in ("loop_us", "batched_us")}
+                    return rows
+                bb = client_blocks(client)
+                if bb:
+                    small["batched_blocks_compiled_c"] = {"gpu": bb, "note": "us per n blocks (BC1, BPTC; n = 1, 1024, 1048576): loop_us = n calls of the leaf function "
+                                                          "detexDecompressBlock<FMT>, batched_us = ONE detexhipDecompressBlocks call (include/detexhip.h); a loop of 2^20 "
+                                                          "trips to the GPU is not timed"}
+                    if os.path.exists(client + "_reflib"):
+                        small["batched_blocks_compiled_c"]["reference_1thread"] = client_blocks(client + "_reflib")
             result["host_tier_small"] = small
         except Exception as e:  # noqa
             log("host_tier_small failed:", e)
