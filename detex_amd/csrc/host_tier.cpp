@@ -20,7 +20,6 @@ struct ThreadContext {
 	bool ready = false;
 	int device = -1;
 	hipStream_t stream = nullptr;
-	hipStream_t stream2 = nullptr;	// second band of the two-band staged path (created on first use)
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
 	uint32_t *d_status = nullptr;	// 32 words: [0] status word, [0..15] histogram bins, [16..19] workgroup counters of the small calls' completions (Completion::counter),
@@ -40,8 +39,6 @@ struct ThreadContext {
 		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
 		if (h_pin) (void)hipHostFree(h_pin);
 		(void)hipStreamDestroy(stream);
-		if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
-		stream2 = nullptr;
 		d_in = d_out = nullptr; d_status = nullptr; in_cap = out_cap = 0;
 		h_pin = d_pin = nullptr; pin_cap = 0;
 		stream = nullptr;
@@ -431,31 +428,6 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
 	uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
 	*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
-	// Mid-size linear textures (3 .. 32 MiB of pixels, blocks in the pinned buffer) go in TWO bands of block rows on two streams: the
-	// second band's kernel runs while the first band's pixels are already on their way to the caller -- the one serial step of this
-	// path that is not a transfer (1024^2: the kernel, fed across the link, is ~15 of 120 us).  Each band stays above 1.5 MiB: below
-	// that the runtime copies into pageable memory through its own staging buffer at a third of the link's rate
-	// (profiles/r05/host_pageable_copy_curve.json: 1 MiB 71 us, 1.5 MiB 37 us).
-	if (!tiled && pinned_in && pinned_status && cov_w == width && cov_h == height && hb >= 2 && height == 4u * hb &&
-			out_bytes >= ((size_t)3 << 20) && out_bytes <= ((size_t)32 << 20) && Tune::kHostTwoBands) {
-		if (!c.stream2) HIP_TRY(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking), "hipStreamCreate");
-		const size_t r_mid = hb / 2u;
-		const hipStream_t streams[2] = { c.stream, c.stream2 };
-		const size_t r0[2] = { 0, r_mid }, r1[2] = { r_mid, hb };
-		for (int b = 0; b < 2; b++)
-			if (detexhipDecompressTextureLinearDevice(texture->format, d_in + r0[b] * wb * bs, (int)width, (int)((r1[b] - r0[b]) * 4u), (int)wb, (int)(r1[b] - r0[b]),
-					d_out + r0[b] * 4u * width * px, width * px, pixel_format, streams[b], d_status) != 0) { (void)hipStreamSynchronize(c.stream); return false; }
-		bool ok = true;
-		for (int b = 0; b < 2 && ok; b++)
-			ok = hipMemcpyAsync(pixel_buffer + r0[b] * 4u * width * px, d_out + r0[b] * 4u * width * px, (r1[b] - r0[b]) * 4u * width * px, hipMemcpyDeviceToHost, streams[b]) == hipSuccess;
-		const hipError_t e1 = hipStreamSynchronize(c.stream), e2 = hipStreamSynchronize(c.stream2);
-		if (!ok || e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); detexSetErrorMessage("libdetexhip: two-band download failed"); return false; }
-		if (*h_status != 0) {
-			detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-			return false;
-		}
-		return true;
-	}
 	int rc;
 	if (tiled)
 		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status);

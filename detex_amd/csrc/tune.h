@@ -48,8 +48,6 @@ struct ProductTune {
 	// ... and larger textures whose BLOCKS fit in this many bytes hand them over through the same pinned buffer (read by the kernel across
 	// the link) instead of an upload out of pageable memory; 0 = always upload
 	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
-	// ... and 3-32 MiB of pixels go in two bands on two streams (the second band's kernel overlaps the first band's download)
-	static constexpr bool kHostTwoBands = true;
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };
