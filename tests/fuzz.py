@@ -2,7 +2,8 @@
 tools/gpu_fuzz.py (open-ended sweep on the GPU box).  One seed = every format once: a random geometry (power-of-two and
 non-power-of-two block widths, both sides of the several-blocks-per-lane condition, clipped sizes, a padded pitch now and
 then), a stream biased towards repeated blocks one time in three, decoded linear (native target and, one time in three, a
-random epilogue target), block-major and through the per-block API with a random mode mask -- and, for textures of up to 1024
+random epilogue target), block-major and through the per-block API with a random mode mask (device pointers, and a random count
+of the blocks through the batched host-pointer entry detexhipDecompressBlocks) -- and, for textures of up to 1024
 blocks, through the HOST-POINTER entry points twice in a row (the second call is answered by the resident kernel) plus two one-block
 leaf calls with a random mode mask -- each against the CPU oracle, bit for bit.  Test infrastructure only."""
 import numpy as np
@@ -75,6 +76,12 @@ def run_seed(seed, oracle, binding, torch):
         assert np.array_equal(got_ok.cpu().numpy()[:wb * hb].astype(bool), ok_b), ("blocks ok", hex(mask)) + where
         assert np.array_equal(got_b.cpu().numpy().reshape(-1)[:wb * hb * 16 * px], want_b.reshape(-1)), ("blocks", hex(mask)) + where
         cases += 2
+        # the batched HOST-pointer block entry with the same mask (pinned exchange or staged, by size; a random count of the blocks)
+        n_h = int(rng.integers(1, wb * hb + 1))
+        all_ok, ok_h, px_h = api.blocks(fmt, data[:n_h * fmt.block_bytes], mode_mask=mask)
+        assert np.array_equal(ok_h.astype(bool), ok_b[:n_h]) and all_ok == bool(ok_b[:n_h].all()), ("host blocks ok", hex(mask), n_h) + where
+        assert np.array_equal(px_h, want_b[:n_h]), ("host blocks", hex(mask), n_h) + where
+        cases += 1
         # host-pointer tier, small textures: two calls in a row (launch, then the resident kernel), either layout; two leaf calls
         if wb * hb <= 1024:
             for rep in range(2):

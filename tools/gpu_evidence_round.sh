@@ -1,41 +1,49 @@
 #!/bin/bash
 # The final measurement round of a build round on the GPU box (via gpurun):  bash tools/gpu_evidence_round.sh r05  -> gpurun_out/r05/, whose
 # summaries are then committed under profiles/r05/ (what profiles/rNN/ holds from the FINAL library of a round comes from here).
+# SKIP="fuzz pmc" leaves sections out.
 set -u
-export TMPDIR=/tmp
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=${1:-round}
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 ROOT=$(pwd)
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s 2>&1 | tail -14 | tee $OUT/pytest_gpu.log
-echo "== bench (driver line, N=1)"; ( time timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; cut -c1-600 $OUT/bench.json
-echo "== compiled C client: fixtures, latency"; tests/c_client/detex_client tests/golden/test-texture-BC1.ktx tests/golden/test-texture-BPTC_FLOAT.ktx | tee $OUT/c_client.txt; tests/c_client/detex_client --latency | tee -a $OUT/c_client.txt
+skip() { case " ${SKIP:-} " in *" $1 "*) return 0 ;; esac; return 1; }
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s 2>&1 | tail -40 | tee $OUT/pytest_gpu.log | tail -3
+mkdir -p $OUT/rccl_preflight; cp gpurun_out/rccl_preflight/*.log gpurun_out/rccl_preflight/*.json $OUT/rccl_preflight/ 2>/dev/null
+echo "== bench (driver line, N=1)"; ( time timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; cut -c1-400 $OUT/bench.json
+echo "== compiled C client: fixtures, latency, batched blocks"
+tests/c_client/detex_client tests/golden/test-texture-BC1.ktx tests/golden/test-texture-BPTC_FLOAT.ktx | tee $OUT/c_client.txt
+tests/c_client/detex_client --latency | tee -a $OUT/c_client.txt | head -3
 echo "-- the same with DETEXHIP_RESIDENT_US=0 (a launch per call)" >> $OUT/c_client.txt; DETEXHIP_RESIDENT_US=0 tests/c_client/detex_client --latency >> $OUT/c_client.txt
 echo "-- the same program linked against the compiled reference (one host thread)" >> $OUT/c_client.txt; [ -x tests/c_client/detex_client_reflib ] && tests/c_client/detex_client_reflib --latency >> $OUT/c_client.txt
-echo "== host code under ASan/UBSan with the device"; ASAN_OPTIONS=detect_leaks=0 timeout 300 tests/host_san/api_san 2>&1 | tail -3 | tee $OUT/api_san_gpu.txt
+echo "-- n independent blocks: the loop over the leaf function against ONE detexhipDecompressBlocks call" >> $OUT/c_client.txt; tests/c_client/detex_client --blocks | tee -a $OUT/c_client.txt
+echo "-- the same loop in the compiled reference" >> $OUT/c_client.txt; [ -x tests/c_client/detex_client_reflib ] && tests/c_client/detex_client_reflib --blocks >> $OUT/c_client.txt
 ldd tests/c_client/detex_client | grep -i "amdhip\|detexhip" >> $OUT/c_client.txt
-echo "== per-format table, all formats, streams U / M / C, linear and tiled"
+echo "== host code under ASan/UBSan with the device"; ASAN_OPTIONS=detect_leaks=0 timeout 300 tests/host_san/api_san 2>&1 | tail -3 | tee $OUT/api_san_gpu.txt
+echo "== host tier: where a mid-size call's time goes; the runtime's pageable copy curve"; timeout 300 tools/ubench/host_midsize > $OUT/host_midsize.jsonl 2>&1; wc -l $OUT/host_midsize.jsonl
+echo "== cold start"; timeout 300 python tools/gpu_cold_trace.py BC1 > $OUT/cold_trace_bc1.json 2> /dev/null; cut -c1-200 $OUT/cold_trace_bc1.json
+echo "== per-format tables: all formats, streams U / M / C, linear and block-major at 8192^2; linear at 16384^2 (beyond the Infinity Cache for every format)"
 timeout 900 python bench.py --no-cpu --no-extras --formats-json $OUT/formats_8192.json > /dev/null 2> $OUT/formats.err; grep -c launch_us $OUT/formats.err
 timeout 900 python bench.py --no-cpu --no-extras --layout tiled --formats-json $OUT/formats_8192_tiled.json > /dev/null 2> $OUT/formats_tiled.err; grep -c launch_us $OUT/formats_tiled.err
+timeout 1200 python bench.py --no-cpu --no-extras --size 16384 --formats-json $OUT/formats_16384.json > /dev/null 2> $OUT/formats_16384.err; grep -c launch_us $OUT/formats_16384.err
 echo "== N=2 plumbing over gloo on this one GPU: the 32768^2 BC1 image in two bands, every rank digests its band (eighths) against the reference"
-DETEX_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --strong-image 32768 --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/bench_n2_gloo_32768.json 2> $OUT/bench_n2_gloo.err; cut -c1-400 $OUT/bench_n2_gloo_32768.json; tail -2 $OUT/bench_n2_gloo.err
-python - $TAG <<'PY'
-import json, sys
-try:
-    d = json.loads(open("gpurun_out/%s/bench_n2_gloo_32768.json" % sys.argv[1]).read().strip().splitlines()[-1])
-    print("N=2 gloo: value", d["value"], "digests match on all ranks:", d.get("whole_band_digests_match_reference_all_ranks"))
-except Exception as e:
-    print("N=2 gloo line unreadable:", e)
-PY
-echo "== rocprofv3 kernel trace + stats of the bench command (headline); the environment a profiled bench.py sees"
+DETEX_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --strong-image 32768 --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/bench_n2_gloo_32768.json 2> $OUT/bench_n2_gloo.err; cut -c1-300 $OUT/bench_n2_gloo_32768.json; tail -2 $OUT/bench_n2_gloo.err
+echo "== the multi-GPU branch under RCCL at world size 1 (DETEX_BENCH_FORCE_DIST=1), RCCL's own log kept; then the driver's N=2 command, which must end with exit code 5 here"
+STEPS=20 WARMUP=5 bash tools/scale_preflight.sh 1 2>&1 | tail -4; bash tools/scale_preflight.sh 2 > $OUT/scale_preflight_n2.txt 2>&1; echo "scale_preflight.sh 2 -> exit code $?" | tee -a $OUT/scale_preflight_n2.txt
+mkdir -p $OUT/scale_preflight; cp gpurun_out/scale_preflight/bench_n1_forced.json $OUT/scale_preflight/ 2>/dev/null
+for f in gpurun_out/scale_preflight/rccl_n1_*.log; do [ -f "$f" ] && grep -v "Channel [0-9]*/[0-9]* :" "$f" | cut -c1-400 | head -150 > $OUT/scale_preflight/$(basename $f); done
+grep -m2 "NOT one rank per GPU" gpurun_out/scale_preflight/rccl_n2.log | cut -c1-400 >> $OUT/scale_preflight_n2.txt
+echo "== rocprofv3 kernel trace + stats of the bench command (headline)"
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -T -d $ROOT/$OUT/prof_trace -o bc1 --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/prof_trace.log
 cd $ROOT; f=$(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bc1_8192_kernel_stats.csv && head -4 "$f" | cut -c1-160
-python -c "
-import json; d=json.loads(open('$OUT/bench_under_rocprof.json').read().strip().splitlines()[-1]); print('under rocprofv3: traffic_source =', d['roofline'].get('traffic_source','')[:60])"
 bash tools/gpu_rocprof_formats.sh 2>&1 | grep last200 | cut -c1-200; mkdir -p $OUT/rocprof_formats; cp gpurun_out/rocprof_formats/*.json gpurun_out/rocprof_formats/*kernel_stats.csv $OUT/rocprof_formats/ 2>/dev/null
-echo "== PMC traffic (separate passes)"
-timeout 1500 python tools/pmc_traffic.py $OUT BC1:linear BC3:linear BPTC:linear BPTC_FLOAT:linear BPTC_SIGNED_FLOAT:linear ETC2:linear ETC2_EAC:linear BC1:tiled BPTC:tiled 2>&1 | tail -10
-echo "== SQ counters per wave (BC7, signed BC6H)"
+if ! skip pmc; then
+  echo "== PMC traffic (separate passes): nine kernels at 8192^2, the five narrow formats at 16384^2"
+  timeout 2400 python tools/pmc_traffic.py $OUT BC1:linear BC3:linear BPTC:linear BPTC_FLOAT:linear BPTC_SIGNED_FLOAT:linear ETC2:linear ETC2_EAC:linear BC1:tiled BPTC:tiled \
+    RGTC1:linear:16384 RGTC2:linear:16384 SIGNED_RGTC1:linear:16384 EAC_R11:linear:16384 EAC_SIGNED_R11:linear:16384 2>&1 | tail -15
+fi
+echo "== SQ counters per wave (BC7, BC6H)"
 for FMT in BPTC BPTC_SIGNED_FLOAT BPTC_FLOAT; do
   cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $ROOT/$OUT/sq_$FMT -o sq --output-format csv -- python $ROOT/tools/gpu_run_case.py $FMT U 8192 8192 0 6 linear > /dev/null 2>&1
   cd $ROOT; f=$(find $OUT/sq_$FMT -name "*counter_collection.csv" | head -1)
@@ -50,8 +58,7 @@ print(sys.argv[2], "stream U, per wave:", {k: round(v / w, 1) for k, v in m.item
 PY
   rm -rf $OUT/sq_$FMT
 done | tee $OUT/sq_per_wave.txt
-echo "== small calls"; timeout 300 python tools/gpu_small_latency.py detex_amd/lib/libdetexhip.so 2>/dev/null | tee $OUT/small_latency.jsonl | cut -c1-200
 echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
-echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 40000 2>&1 | tail -1 | tee $OUT/fuzz.log
-rm -rf $OUT/prof_trace $OUT/pmc_*_*_* 2>/dev/null
+if ! skip fuzz; then echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 50000 2>&1 | tail -1 | tee $OUT/fuzz.log; fi
+rm -rf $OUT/prof_trace $OUT/pmc_*_*_*_* $OUT/pmc_*_*_* 2>/dev/null
 echo "== done"
