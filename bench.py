@@ -241,6 +241,12 @@ def main():
     ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (gloo announces its connections, RCCL its version banner when
+    # NCCL_DEBUG is set, rocprofv3 its summary): from here on file descriptor 1 is stderr's, and the line at the end goes to the saved one.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from detex_amd import binding, formats as F, sharding
@@ -409,6 +415,17 @@ def main():
         if resident:
             row["frac_note"] = ("blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s) and no roofline fraction is given; "
                                 "per_format.beyond_cache_16384 has this format at a size that does not fit")
+        # the write-only fraction (north_star's "HBM-write roofline"): pixels written / time / 8 TB/s -- a lower bound that no cache can inflate
+        # at sizes whose PIXELS do not fit the Infinity Cache
+        row["write_frac"] = None if resident else round(job.blocks * 16 * job.tpx / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+        if not resident and ach > HBM_PEAK_GBPS:
+            # (coherent content -- stream C -- in the cheapest decoders at 16384^2: 8.0-8.25 TB/s at the L2's memory interface, where the PMC counters see
+            # exactly the algorithmic bytes for stream C as for stream U: profiles/r05/stream_c_16384_counters.jsonl.  The 128-256 MiB of BLOCKS
+            # can be served by the Infinity Cache behind that interface from launch to launch, and the pins' rate is 8.19 TB/s, not the guide's
+            # round 8: a rate above the peak is not an HBM rate, so no fraction is claimed -- write_frac stands)
+            row["frac"] = None
+            row["frac_note"] = ("above the 8 TB/s peak: the blocks of this size (<= 256 MiB) can be served by the Infinity Cache behind the L2's memory interface; "
+                                "no HBM fraction is given, write_frac is the cache-proof figure")
         if clocks:                         # shader clock and board power while this kernel runs back to back (0.15 s, hwmon files)
             t = telemetry.during(job.step)
             torch.cuda.synchronize()
@@ -744,7 +761,7 @@ def main():
         torch.cuda.empty_cache()
         if result["roofline"].get("ref_copy_GBps"):     # a mixed read + write stream: beside the 8 TB/s fraction, the fraction of the copy measured in this process
             for row in table.values():
-                if not row["cache_resident"]:
+                if row["frac"] is not None:
                     row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
         # the six headline formats beyond the Infinity Cache: 16384^2 (1 GiB of 32-bit pixels, 2 GiB of BC6H's)
         big_table = {}
@@ -766,7 +783,7 @@ def main():
             torch.cuda.empty_cache()
         if result["roofline"].get("ref_copy_GBps"):
             for row in big_table.values():
-                if "achieved_GBps" in row and not row["cache_resident"]:
+                if row.get("frac") is not None:
                     row["frac_of_measured_copy"] = round(row["achieved_GBps"] / result["roofline"]["ref_copy_GBps"], 4)
         result["per_format"] = {"size": "8192x8192", "note": "launch time at steady state (windows of 100 launches until two agree within 1.2 % and >= 600 launches ran); "
                                                              "sclk_mhz / power_w: hwmon samples while the kernel then runs back to back for 0.15 s; cache_resident: "
@@ -893,7 +910,9 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.formats_json)), exist_ok=True)
         json.dump(table, open(args.formats_json, "w"), indent=1, sort_keys=True)
 
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    real_stdout.write(json.dumps(result) + "\n")
+    real_stdout.flush()
     if multi:
         dist.destroy_process_group()
 

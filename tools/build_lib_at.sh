@@ -1,6 +1,6 @@
 #!/bin/bash
 # build the library as it was at a given commit into build/explib/libdetexhip_<tag>.so (same-run comparisons):
-#   bash tools/build_lib_at.sh 0ebf32e r01      # the round-1 library used by tools/gpu_cmp_r01.sh
+#   bash tools/build_lib_at.sh 0ebf32e r01      # the round-1 library
 #   bash tools/build_lib_at.sh HEAD prev        # the last commit, against uncommitted changes
 set -e
 cd "$(dirname "$0")/.."

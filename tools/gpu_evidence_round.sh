@@ -34,9 +34,9 @@ STEPS=20 WARMUP=5 bash tools/scale_preflight.sh 1 2>&1 | tail -4; bash tools/sca
 mkdir -p $OUT/scale_preflight; cp gpurun_out/scale_preflight/bench_n1_forced.json $OUT/scale_preflight/ 2>/dev/null
 for f in gpurun_out/scale_preflight/rccl_n1_*.log; do [ -f "$f" ] && grep -v "Channel [0-9]*/[0-9]* :" "$f" | cut -c1-400 | head -150 > $OUT/scale_preflight/$(basename $f); done
 grep -m2 "NOT one rank per GPU" gpurun_out/scale_preflight/rccl_n2.log | cut -c1-400 >> $OUT/scale_preflight_n2.txt
-echo "== rocprofv3 kernel trace + stats of the bench command (headline)"
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -T -d $ROOT/$OUT/prof_trace -o bc1 --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/prof_trace.log
-cd $ROOT; f=$(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bc1_8192_kernel_stats.csv && head -4 "$f" | cut -c1-160
+echo "== rocprofv3 kernel trace + stats: the headline workload alone, and the driver's exact command"
+bash tools/gpu_kernel_stats.sh 2>&1 | tail -4; cp gpurun_out/kernel_stats/headline_kernel_stats.csv $OUT/bc1_8192_kernel_stats.csv; cp gpurun_out/kernel_stats/driver_kernel_stats.csv $OUT/driver_command_kernel_stats.csv
+cp gpurun_out/kernel_stats/headline_bench.json $OUT/bench_headline_under_rocprofv3.json
 bash tools/gpu_rocprof_formats.sh 2>&1 | grep last200 | cut -c1-200; mkdir -p $OUT/rocprof_formats; cp gpurun_out/rocprof_formats/*.json gpurun_out/rocprof_formats/*kernel_stats.csv $OUT/rocprof_formats/ 2>/dev/null
 if ! skip pmc; then
   echo "== PMC traffic (separate passes): nine kernels at 8192^2, the five narrow formats at 16384^2"
@@ -60,5 +60,5 @@ PY
 done | tee $OUT/sq_per_wave.txt
 echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
 if ! skip fuzz; then echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 50000 2>&1 | tail -1 | tee $OUT/fuzz.log; fi
-rm -rf $OUT/prof_trace $OUT/pmc_*_*_*_* $OUT/pmc_*_*_* 2>/dev/null
+rm -rf $OUT/pmc_*_*_*_* $OUT/pmc_*_*_* 2>/dev/null
 echo "== done"
