@@ -26,6 +26,7 @@
 //
 // Reference quirk reproduced: in mode 6 the second P-bit (block bit 64) reads 0.
 #pragma once
+#include <cstddef>
 #include "bptc_common.h"
 #include "decode_s3tc_rgtc.h"
 
@@ -219,6 +220,7 @@ struct Bc7Lds {
 	alignas(16) uint32_t bits[4][256];	// (16-byte aligned: the block-major exchange stages 16-byte vectors here, stage_slot)
 };
 static_assert(sizeof(Bc7Lds) <= 20480, "eight workgroups per CU by LDS (the round-2 occupancy sweep padded this struct: profiles/AB_RECORD.md)");
+static_assert(offsetof(Bc7Lds, bits) + sizeof(Bc7Lds::bits) == sizeof(Bc7Lds), "bits[] must stay the LAST member: fields near the end of a block read up to two rows past it (see the comment in the struct)");
 DH Bc7Lds &bc7_lds() { __shared__ __attribute__((aligned(16384))) Bc7Lds s; return s; }	// the VARIABLE is aligned: the size is not rounded up
 // (Requesting the kernel's first block between the table load and its LDS store -- so that the block travels during the
 // barrier -- was measured too: the compiler issues the block load first either way, and then the barrier waits for the
