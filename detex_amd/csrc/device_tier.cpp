@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "host_internal.h"
+#include "tune.h"
 
 namespace detexhip {
 
@@ -117,6 +118,10 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 	if (epi == -2) return 1;
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
 		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), variant, epi, decode_flags, f->resident };
+	// (a texture whose blocks + pixels exceed the Infinity Cache may want another residency cap: FormatEntry::resident_beyond_cache)
+	if (f->resident_beyond_cache >= 0 &&
+			(size_t)width_in_blocks * (size_t)height_in_blocks * (detexGetCompressedBlockSize(texture_format) + 16u * px) > Tune::kInfinityCacheBytes)
+		g.resident = f->resident_beyond_cache;
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;

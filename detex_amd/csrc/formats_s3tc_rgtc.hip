@@ -9,7 +9,7 @@ namespace detexhip {
 const FormatEntry *formats_s3tc_rgtc() {
 	static const FormatEntry rows[8] = {
 		FMT(BC1, DecBC1, kClassS3TC, 5, 5), FMT(BC1A, DecBC1A, kClassS3TC, 5, 5), FMT(BC2, DecBC2, kClassS3TCat8, 5, 5), FMT(BC3, DecBC3, kClassS3TCat8, 5, 5),
-		FMT(RGTC1, DecRGTC1, kClassNone, 0, 0), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone, 0, 0), FMT(RGTC2, DecRGTC2, kClassNone, 6, 0),
+		FMT_L(RGTC1, DecRGTC1, kClassNone, 0, 0, 5), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone, 0, 0), FMT(RGTC2, DecRGTC2, kClassNone, 6, 0),
 		FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone, 5, 5),
 	};
 	return rows;

@@ -69,6 +69,7 @@ struct FormatEntry {
 	const char *kernel_name;
 	int resident;			// resident workgroups per CU of the linear kernels (launchers.h: occupancy_cap_lds); 0 = whatever fits
 	int resident_blocks;		// the same for the block-major texture driver
+	int resident_beyond_cache;	// ... for the linear kernels when blocks + pixels exceed the Infinity Cache (Tune::kInfinityCacheBytes); -1 = the same as `resident`
 };
 // format index (texture_format >> 24, detex.h:913-915): 1-8, 9-10, 11, 12-19
 const FormatEntry *formats_s3tc_rgtc(), *formats_bptc_float(), *formats_bptc(), *formats_etc_eac();	// 8, 2, 1, 8 rows (formats_*.hip)

@@ -203,7 +203,11 @@ template <class Dec> hipError_t launch_resident(const ResidentLaunch &r) {
 // 3..7 against none): the store-bound kernels with 32-bit or wider pixels and little VALU work gain 1-2.6 % at four or five per CU;
 // BC6H gains 11 % on coherent content at five at the price of 2.6 % on uniform-random blocks; BC7, signed BC6H, ETC2_EAC (linear)
 // and the narrow RGTC1 / EAC_R11 formats lose with any cap and keep what fits.
-#define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
-	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS }
+// RESIDENT_LARGE: the linear kernels' cap when blocks + pixels do not fit the 256 MiB Infinity Cache (-1: the same).  RGTC1 is the one
+// format where the two regimes want different answers (same-run sweep, round 5: 16384^2 -- 384 MiB -- no cap 59.2 us, three to five
+// per CU 55.3-55.5; 8192^2 -- 96 MiB, cache-resident -- no cap 12.4, capped 13.8-14.1): its stores are HBM-bound only when they reach HBM.
+#define FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
+	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE }
+#define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, -1)
 
 }  // namespace detexhip

@@ -31,6 +31,8 @@ struct ProductTune {
 	// resident workgroups per CU of the linear kernels: -1 = the per-format choice of the formats_*.hip tables, 0 = no cap, 3..7 = this
 	// many for every format (sweeps; the cap is dynamic LDS requested at launch: profiles/AB_RECORD.md)
 	static constexpr int kWorkgroupsPerCu = -1;
+	// memory-side cache of the device (MI355X: 256 MiB Infinity Cache): a texture whose blocks + pixels fit is not HBM-bound
+	static constexpr unsigned long kInfinityCacheBytes = 256ul << 20;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store
