@@ -317,6 +317,49 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		if (cov_w == width) memcpy(pixel_buffer + y0 * width * px, res + y0 * width * px, (y1 - y0) * width * px);
 		else for (size_t y = y0; y < y1; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
 	};
+	// Mid-size linear textures (a quarter MiB to Tune::kHostRegisterOutputBytes of pixels): the CALLER's pixel buffer is registered with the
+	// runtime for the duration of the call and the kernel writes straight into it -- no staging buffer on either side of the link, no copy
+	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate up to a few MiB (4 MiB: 87 vs 84
+	// us), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of freshly written
+	// pinned memory, the staged path's serial kernel -> download -- cost more: 512^2 54 -> 40 us, 1024^2 120 -> 112 (tools/ubench/
+	// host_midsize.hip: sequences G / G2).  Beyond ~6 MiB the DMA download wins again (16 MiB: 391 vs 305 us).  The kernel writes exactly the
+	// pixels the reference would (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the
+	// caller, sharing a page with another thread's registered buffer) takes the paths below.
+	if (!tiled && out_bytes > ((size_t)256 << 10) && out_bytes <= Tune::kHostRegisterOutputBytes && in_bytes <= Tune::kHostPinnedInputBytes) {
+		struct Registered {		// (unregistered on every way out)
+			void *host = nullptr, *dev = nullptr;
+			Registered(void *p, size_t n) {
+				if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+				host = p;
+				if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
+			}
+			~Registered() { if (host) (void)hipHostUnregister(host); }
+		} reg(pixel_buffer, out_bytes);
+		const int epi = reg.dev ? prepared_epilogue(texture->format, pixel_format) : -1;
+		if (epi == -2) return false;
+		DirectExchange x;
+		if (reg.dev && epi >= 0 && direct_exchange(c, in_bytes, 0, &x)) {
+			(void)c.service.wanted(nullptr, -1);		// a larger call ends a row of small ones
+			memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+			*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
+			const uint32_t ticket = next_ticket(c);
+			LevelsArgs a{};
+			a.status = reinterpret_cast<uint32_t *>(x.d_base); a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
+			a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket };
+			a.table.n_levels = 1;
+			LevelDesc &lv = a.table.level[0];
+			lv.blocks = x.d_base + x.in_off; lv.pixels = static_cast<uint8_t *>(reg.dev); lv.pitch = width * px;
+			lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * hb); lv.width = (uint32_t)width; lv.height = (uint32_t)height;
+			a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
+			HIP_TRY(f->levels(a), "kernel launch");
+			if (!wait_for_ticket(c, x, ticket)) return false;
+			if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
+				detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
+				return false;
+			}
+			return true;
+		}
+	}
 	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
 		// the smallest textures (either layout), from the second call in a row on: a request to the resident kernel instead of a launch
 		if (wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {

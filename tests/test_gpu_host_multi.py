@@ -330,3 +330,69 @@ def test_host_tier_status_does_not_leak_between_calls(W, H, hiplib, oracle):
         assert np.array_equal(got[:ref_rows.size], ref_rows), (W, H, k)
         if not ok:
             assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+
+
+# ---- mid-size textures: the kernel writes straight into the caller's buffer, registered for the call (host_tier.cpp) ---------------------
+@pytest.mark.parametrize("name,W,H,wb,hb", [("BC1", 512, 512, None, None), ("BPTC", 1024, 1024, None, None), ("BPTC", 701, 333, None, None), ("BC3", 1001, 513, None, None),
+                                            ("RGTC1", 2048, 1024, None, None), ("BPTC_FLOAT", 512, 384, None, None), ("ETC2", 900, 400, 200, 90), ("EAC_RG11", 1022, 258, None, None)])
+def test_host_tier_registered_output_window(name, W, H, wb, hb, hiplib, oracle):
+    """0.25-6 MiB of pixels: whole and clipped sizes, a block grid smaller than the image (the rest of the caller's buffer must survive),
+    invalid blocks (zero-filled, false + the reference's text), 64-bit pixels, narrow pixels -- twice each (registration is per call)"""
+    fmt = F.BY_NAME[name]
+    gwb, ghb = (W + 3) // 4 if wb is None else wb, (H + 3) // 4 if hb is None else hb
+    data = ol.stream_u(fmt, gwb * ghb, seed=0x4E6 + fmt.index + W)
+    px = fmt.pixel_bytes
+    assert 256 << 10 < W * H * px <= 6 << 20
+    for rep in range(2):
+        out = np.full(W * H * px + 64, 0xA5, np.uint8)
+        ok, got = hiplib.linear(fmt, data, W, H, out=out[:W * H * px], wb=gwb, hb=ghb)
+        cw, ch = min(W, 4 * gwb), min(H, 4 * ghb)
+        want_ok, want = oracle.linear(fmt, data, cw, ch)                 # (cw, ch: the part of the image the block grid covers)
+        img = got.reshape(H, W * px)
+        assert np.array_equal(img[:ch, :cw * px].reshape(-1), want.reshape(-1)), (name, W, H, rep)
+        assert (img[:ch, cw * px:] == 0xA5).all() and (img[ch:] == 0xA5).all(), "pixels outside the block grid were written"
+        assert (out[W * H * px:] == 0xA5).all(), "wrote past the image"
+        assert ok == want_ok
+        if not ok:
+            assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+
+
+def test_host_tier_registered_output_fallbacks(hiplib, oracle, torch_cuda):
+    """buffers the library cannot register for itself -- already pinned by the caller (a torch pinned tensor), or sharing pages with a buffer
+    another thread's call has registered at that moment -- and a pixel pointer that is not 16-byte aligned: the result is the same"""
+    import threading
+    torch = torch_cuda
+    fmt = F.BY_NAME["BC1"]
+    W = H = 512
+    data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0xFA11)
+    _, want = oracle.linear(fmt, data, W, H)
+    pinned = torch.empty(W * H * 4, dtype=torch.uint8).pin_memory()
+    ok, got = hiplib.linear(fmt, data, W, H, out=pinned.numpy())
+    assert ok and np.array_equal(got, want)
+    raw = np.full(W * H * 4 + 16, 0xA5, np.uint8)
+    ok, got = hiplib.linear(fmt, data, W, H, out=raw[4:4 + W * H * 4])             # misaligned by 4: the staged-rows kernel
+    assert ok and np.array_equal(got, want) and (raw[:4] == 0xA5).all() and (raw[4 + W * H * 4:] == 0xA5).all()
+    # four threads, adjacent images inside ONE allocation (neighbours share a page at every boundary), 40 calls each
+    n = 4
+    sz = 500 * 300 * 4                                                               # not a multiple of the page size
+    big = np.zeros(n * sz, np.uint8)
+    d2 = ol.stream_u(fmt, 125 * 75, seed=0xFA12)
+    _, want2 = oracle.linear(fmt, d2, 500, 300)
+    errors = []
+
+    def worker(k):
+        try:
+            api = ol.DetexAPI(hiplib.path)
+            for _ in range(40):
+                view = big[k * sz:(k + 1) * sz]
+                view[:] = 0
+                ok, got = api.linear(fmt, d2, 500, 300, out=view)
+                if not ok or not np.array_equal(got, want2):
+                    errors.append((k, "mismatch"))
+                    return
+        except Exception as e:   # noqa
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors

@@ -40,6 +40,20 @@ __global__ __launch_bounds__(256) void standin(const uint2 *in, v4 *out, uint32_
 	}
 }
 __global__ void empty_kernel() {}
+// the decode kernels' store shape: every store instruction of a wave covers one contiguous 1 KiB run (lane l writes 16 bytes at run + 16 l)
+__global__ __launch_bounds__(256) void fill_runs(v4 *out, uint32_t n_vec, uint32_t *done, uint32_t *counter, uint32_t ticket) {
+	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	for (int k = 0; k < 4; k++) {
+		const uint32_t e = (wave * 4u + (uint32_t)k) * 64u + lane;
+		if (e < n_vec) __builtin_nontemporal_store(v4{ e, 1u, 2u, 3u }, out + e);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+	__syncthreads();
+	if (threadIdx.x == 0 && __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+		__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
 
 template <class F> static double median_us(int reps, F &&fn) {
 	std::vector<double> t(reps);
@@ -144,6 +158,36 @@ int main(int argc, char **argv) {
 		}
 		const double F = median_us(reps, [&] {
 			memcpy(p_in, h_in, in_bytes); p_words[0] = 0; const uint32_t tk = ++ticket; kern(pd_in, rd_out, 0, n, pd_words, pd_words + 16, tk); poll(p_words + 16, tk); });
+		// shader stores into host memory in the decode kernels' store shape (1 KiB runs), and what registering the caller's buffer would cost per call
+		const uint32_t n_vec = (uint32_t)(out_bytes / 16);
+		const double runs_pinned = median_us(reps, [&] { const uint32_t tk = ++ticket; hipLaunchKernelGGL(fill_runs, dim3((n_vec + 1023u) / 1024u), dim3(256), 0, s, (v4 *)pd_out, n_vec, pd_words + 16, d_words + 8, tk); poll(p_words + 16, tk); });
+		const double runs_device = median_us(reps, [&] { hipLaunchKernelGGL(fill_runs, dim3((n_vec + 1023u) / 1024u), dim3(256), 0, s, (v4 *)d_out, n_vec, d_words + 12, d_words + 8, 1u); CK(hipStreamSynchronize(s)); });
+		// G: the caller's pageable buffer registered FOR THE CALL (four buffers in rotation, so that no registration is reused), run-shaped shader
+		// stores straight into it, completion polled, unregistered; G2: the same with the registration kept (a caller that reuses its buffer)
+		uint8_t *user[4];
+		for (int k = 0; k < 4; k++) { user[k] = (uint8_t *)malloc(out_bytes + 4096) + 64 * (k + 1); memset(user[k], 7, out_bytes); }	// (deliberately not page-aligned)
+		int turn = 0;
+		bool g_ok = true;
+		const double G = median_us(reps, [&] {
+			uint8_t *u = user[turn++ & 3];
+			memcpy(p_in, h_in, in_bytes);
+			CK(hipHostRegister(u, out_bytes, hipHostRegisterDefault));
+			void *du = nullptr; CK(hipHostGetDevicePointer(&du, u, 0));
+			const uint32_t tk = ++ticket;
+			hipLaunchKernelGGL(fill_runs, dim3((n_vec + 1023u) / 1024u), dim3(256), 0, s, (v4 *)du, n_vec, pd_words + 16, d_words + 8, tk); poll(p_words + 16, tk);
+			CK(hipHostUnregister(u));
+			g_ok = g_ok && ((uint32_t *)u)[4] == 1u && ((uint32_t *)(u + out_bytes - 16))[0] == n_vec - 1u; });
+		CK(hipHostRegister(user[0], out_bytes, hipHostRegisterDefault));
+		void *du0 = nullptr; CK(hipHostGetDevicePointer(&du0, user[0], 0));
+		const double G2 = median_us(reps, [&] {
+			memcpy(p_in, h_in, in_bytes); const uint32_t tk = ++ticket;
+			hipLaunchKernelGGL(fill_runs, dim3((n_vec + 1023u) / 1024u), dim3(256), 0, s, (v4 *)du0, n_vec, pd_words + 16, d_words + 8, tk); poll(p_words + 16, tk); });
+		CK(hipHostUnregister(user[0]));
+		printf("{\"side\": %d, \"G_register_per_call_run_stores_into_caller_buffer\": %.1f, \"G2_registration_kept\": %.1f, \"G_results_ok\": %s}\n", side, G, G2, g_ok ? "true" : "false");
+		uint8_t *h_tmp = (uint8_t *)aligned_alloc(4096, out_bytes); memset(h_tmp, 3, out_bytes);
+		const double reg_us = median_us(15, [&] { CK(hipHostRegister(h_tmp, out_bytes, hipHostRegisterDefault)); CK(hipHostUnregister(h_tmp)); });
+		free(h_tmp);
+		printf("{\"side\": %d, \"shader_stores_1KiB_runs_into_pinned_poll\": %.1f, \"same_into_device_sync\": %.1f, \"hipHostRegister_plus_Unregister\": %.1f}\n", side, runs_pinned, runs_device, reg_us);
 		const bool same = memcmp(h_out, h_reg, out_bytes) == 0;
 		printf("{\"side\": %d, \"in_KiB\": %zu, \"out_KiB\": %zu, \"h2d_pageable\": %.1f, \"d2h_pageable\": %.1f, \"d2h_pinned\": %.1f, \"memcpy_in_to_pinned\": %.1f, \"memcpy_out_from_pinned\": %.1f, "
 			"\"kernel_device_sync\": %.1f, \"kernel_host_both_ways_poll\": %.1f, \"A_staged_r04\": %.1f, \"B_staged_lean\": %.1f, \"C_pinned_in_d2h_out\": %.1f, \"D_direct\": %.1f, "
