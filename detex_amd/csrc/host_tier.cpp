@@ -317,14 +317,15 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		if (cov_w == width) memcpy(pixel_buffer + y0 * width * px, res + y0 * width * px, (y1 - y0) * width * px);
 		else for (size_t y = y0; y < y1; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
 	};
-	// Mid-size linear textures (a quarter MiB to Tune::kHostRegisterOutputBytes of pixels): the CALLER's pixel buffer is registered with the
+	// Linear textures with a quarter MiB to Tune::kHostRegisterOutputBytes (2 MiB) of pixels: the CALLER's pixel buffer is registered with the
 	// runtime for the duration of the call and the kernel writes straight into it -- no staging buffer on either side of the link, no copy
-	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate up to a few MiB (4 MiB: 87 vs 84
-	// us), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of freshly written
-	// pinned memory, the staged path's serial kernel -> download -- cost more: 512^2 54 -> 40 us, 1024^2 120 -> 112 (tools/ubench/
-	// host_midsize.hip: sequences G / G2).  Beyond ~6 MiB the DMA download wins again (16 MiB: 391 vs 305 us).  The kernel writes exactly the
-	// pixels the reference would (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the
-	// caller, sharing a page with another thread's registered buffer) takes the paths below.
+	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate at these sizes (1 MiB: 19 us of
+	// data, 4 MiB: 87 vs 84), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of
+	// freshly written pinned memory -- cost more: 512^2 50.5 -> 41.1 us, BC7 56.7 -> 45.7 (same-run A/B from compiled C,
+	// profiles/r05/host_registered_output_ab.txt).  At 4 MiB the staged path's DMA download is as fast (1024^2: 120.5 vs 118.5), beyond
+	// that faster (16 MiB: 391 vs 305 us of data): the window ends at 2 MiB.  The kernel writes exactly the pixels the reference would
+	// (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the caller, sharing a page with
+	// another thread's registered buffer) takes the paths below.
 	if (!tiled && out_bytes > ((size_t)256 << 10) && out_bytes <= Tune::kHostRegisterOutputBytes && in_bytes <= Tune::kHostPinnedInputBytes) {
 		struct Registered {		// (unregistered on every way out)
 			void *host = nullptr, *dev = nullptr;

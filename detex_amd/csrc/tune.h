@@ -52,7 +52,7 @@ struct ProductTune {
 	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
 	// ... and linear textures with more than a quarter MiB and up to this many bytes of PIXELS are written by the kernel straight into the
 	// caller's buffer, registered for the call (0 = never)
-	static constexpr unsigned long kHostRegisterOutputBytes = 6ul << 20;
+	static constexpr unsigned long kHostRegisterOutputBytes = 2ul << 20;
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };
