@@ -336,7 +336,7 @@ def test_host_tier_status_does_not_leak_between_calls(W, H, hiplib, oracle):
 @pytest.mark.parametrize("name,W,H,wb,hb", [("BC1", 512, 512, None, None), ("BPTC", 724, 724, None, None), ("BPTC", 701, 333, None, None), ("BC3", 1001, 513, None, None),
                                             ("RGTC1", 2048, 1024, None, None), ("BPTC_FLOAT", 512, 384, None, None), ("ETC2", 900, 400, 200, 90), ("EAC_RG11", 1022, 258, None, None)])
 def test_host_tier_registered_output_window(name, W, H, wb, hb, hiplib, oracle):
-    """0.25-2 MiB of pixels (and just beyond: 724^2 and 1001x513 take the staged path): whole and clipped sizes, a block grid smaller than the image (the rest of the caller's buffer must survive),
+    """0.25-2 MiB of pixels (724^2 and 2048x1024 R8 sit at the window's upper edge): whole and clipped sizes, a block grid smaller than the image (the rest of the caller's buffer must survive),
     invalid blocks (zero-filled, false + the reference's text), 64-bit pixels, narrow pixels -- twice each (registration is per call)"""
     fmt = F.BY_NAME[name]
     gwb, ghb = (W + 3) // 4 if wb is None else wb, (H + 3) // 4 if hb is None else hb
