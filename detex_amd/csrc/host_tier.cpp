@@ -260,14 +260,196 @@ extern "C" bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_
 	return r == 1;
 }
 
-// shared body of the two texture drivers (texture.c:77-98, 105-145)
-//
-// upload -> one launch -> download on the thread's stream.  The PCIe download of the pixels bounds this tier (8192^2
-// BC1: 256 MiB at the 56 GB/s pageable copies reach on the test box = 4.8 ms; upload 0.6 ms, kernel 0.04 ms: 5.4 ms).
-// A band pipeline (upload k+1 | kernel k | download k-1 on three streams, uploads from a helper thread because
-// hipMemcpyAsync on pageable memory blocks its caller) was built and measured: 5.40 vs 5.45 ms -- a download that
-// shares the link with an upload runs at 41-50 GB/s instead of 56 and every extra copy call costs 30-50 us
-// (tools/ubench/host_paths.hip) -- so it was not kept.
+// One call of a texture driver on its way through the host tier: what every path needs, and the paths themselves -- each either finishes
+// the call (kTrue / kFalse = the reference's bool result; kFalse also for a HIP failure, with its message set) or does not apply (kNotTaken).
+enum Outcome { kNotTaken, kTrue, kFalse };
+struct TextureCall {
+	ThreadContext &c; const FormatEntry *f; const detexTexture *texture; uint8_t *pixel_buffer; uint32_t pixel_format; bool tiled;
+	size_t px, wb, hb, width, height, bs, in_bytes, out_bytes, cov_w, cov_h;
+
+	// same text the reference leaves behind after a failed block (texture.c:63-64)
+	Outcome block_failed() const { detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format); return kFalse; }
+	void copy_out(const uint8_t *res) const {
+		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
+		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+	}
+	void copy_out_rows(const uint8_t *res, size_t y0, size_t y1) const {		// linear layout: image rows [y0, y1)
+		if (y1 > cov_h) y1 = cov_h;
+		if (y0 >= y1) return;
+		if (cov_w == width) memcpy(pixel_buffer + y0 * width * px, res + y0 * width * px, (y1 - y0) * width * px);
+		else for (size_t y = y0; y < y1; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
+	}
+	// one launch of the one-level form of the mip-chain kernel (any geometry, publishes `completion`): block rows [r0, r1) of the texture,
+	// blocks at `blocks_base`, pixels into an image that starts at `pixels_base`
+	bool launch_rows(int epi, const uint8_t *blocks_base, uint8_t *pixels_base, uint32_t *status, size_t r0, size_t r1, const Completion &completion, bool *empty) const {
+		const size_t y0 = r0 * 4u < height ? r0 * 4u : height, y1 = r1 * 4u < height ? r1 * 4u : height;
+		LevelsArgs a{};
+		a.status = status; a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags(); a.completion = completion;
+		a.table.n_levels = 1;
+		LevelDesc &lv = a.table.level[0];
+		lv.blocks = blocks_base + r0 * wb * bs; lv.pixels = pixels_base + y0 * width * px; lv.pitch = width * px;
+		lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * (r1 - r0)); lv.width = (uint32_t)width; lv.height = (uint32_t)(y1 - y0);
+		a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
+		*empty = lv.n_blocks == 0 || y1 == y0;		// (rows of blocks below the image: nothing to decode)
+		if (*empty) return true;
+		HIP_TRY(f->levels(a), "kernel launch");
+		return true;
+	}
+
+	// The smallest textures (either layout), from the second call in a row of one (format, target) pair on: a request to the resident
+	// kernel instead of a launch (host_resident.cpp).  Any other call ends the row -- and the instance that served it.
+	Outcome via_resident_service() const {
+		if (!(in_bytes + out_bytes <= Tune::kHostDirectBytes && wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes)) {
+			(void)c.service.wanted(nullptr, -1);
+			return kNotTaken;
+		}
+		const int epi = prepared_epilogue(texture->format, pixel_format);
+		if (epi == -2) return kFalse;
+		if (!c.service.wanted(f, epi)) return kNotTaken;
+		// (up to one tile: the blocks travel as tagged chunks the kernel reads along with its polls -- path_types.h: kResidentTagged)
+		const bool tagged = wb * hb <= 256u;
+		const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(),
+			tagged ? kResidentTagged : kResidentTexture, tiled ? 1u : 0u };
+		bool failed = false;
+		const uint32_t number = c.service.begin(f, epi);
+		if (number == 0u) return kNotTaken;
+		if (tagged) c.service.pack_tagged(texture->data, in_bytes, number);
+		else memcpy(c.service.blocks_host(), texture->data, in_bytes);
+		if (!c.service.serve(payload, number, &failed)) return kNotTaken;	// (the service has switched itself off with a message; this call still gets its launch)
+		copy_out(c.service.pixels_host());
+		return failed ? block_failed() : kTrue;
+	}
+
+	// Linear textures with a quarter MiB to Tune::kHostRegisterOutputBytes (2 MiB) of pixels: the CALLER's pixel buffer is registered with the
+	// runtime for the duration of the call and the kernel writes straight into it -- no staging buffer on either side of the link, no copy
+	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate at these sizes (1 MiB: 19 us of
+	// data, 4 MiB: 87 vs 84), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of
+	// freshly written pinned memory -- cost more: 512^2 50.5 -> 41.1 us, BC7 56.7 -> 45.7 (same-run A/B from compiled C,
+	// profiles/r05/host_registered_output_ab.txt).  At 4 MiB the staged path's DMA download is as fast (1024^2: 120.5 vs 118.5), beyond
+	// that faster (16 MiB: 391 vs 305 us of data): the window ends at 2 MiB.  The kernel writes exactly the pixels the reference would
+	// (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the caller, sharing a page with
+	// another thread's registered buffer) takes the paths below.
+	Outcome via_registered_output() const {
+		if (tiled || out_bytes <= ((size_t)256 << 10) || out_bytes > Tune::kHostRegisterOutputBytes || in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
+		struct Registered {		// (unregistered on every way out)
+			void *host = nullptr, *dev = nullptr;
+			Registered(void *p, size_t n) {
+				if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+				host = p;
+				if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
+			}
+			~Registered() { if (host) (void)hipHostUnregister(host); }
+		} reg(pixel_buffer, out_bytes);
+		if (!reg.dev) return kNotTaken;
+		const int epi = prepared_epilogue(texture->format, pixel_format);
+		if (epi == -2) return kFalse;
+		DirectExchange x;
+		if (!direct_exchange(c, in_bytes, 0, &x)) return kFalse;
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
+		const uint32_t ticket = next_ticket(c);
+		bool empty = false;
+		if (!launch_rows(epi, x.d_base + x.in_off, static_cast<uint8_t *>(reg.dev), reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
+				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket }, &empty)) return kFalse;
+		if (!empty && !wait_for_ticket(c, x, ticket)) return kFalse;
+		return *reinterpret_cast<volatile uint32_t *>(x.h_base) != 0 ? block_failed() : kTrue;
+	}
+
+	// Blocks + pixels up to Tune::kHostDirectBytes: the kernel reads the blocks from, and writes pixels and status into, pinned host memory
+	// (direct_exchange); the caller polls a completion word and copies the pixels out.  Above a quarter MiB of pixels (a buffer the path
+	// above could not register) the linear layout goes in kDirectBands bands of block rows -- a band is one contiguous range of blocks and
+	// of image rows, texture.c:115-141 -- one launch and one completion word each, all launched at once: band k is copied out while the
+	// kernels of the later bands are still writing theirs across the link (the copy-out of freshly written pinned memory runs at ~20 GB/s
+	// on one host thread, half the link's rate).
+	Outcome via_pinned_exchange() const {
+		if (in_bytes + out_bytes > Tune::kHostDirectBytes) return kNotTaken;
+		DirectExchange x;
+		if (!direct_exchange(c, in_bytes, out_bytes, &x)) return kFalse;
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base);
+		*h_status = 0;
+		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
+		if (tiled) {
+			if (detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st) != 0) return kFalse;
+			if (hipStreamSynchronize(c.stream) != hipSuccess) { detexSetErrorMessage("libdetexhip: hipStreamSynchronize failed"); return kFalse; }
+			copy_out(x.h_base + x.out_off);
+			return *h_status != 0 ? block_failed() : kTrue;
+		}
+		const int epi = prepared_epilogue(texture->format, pixel_format);
+		if (epi == -2) return kFalse;
+		const int bands = (out_bytes > ((size_t)256 << 10) && hb >= (size_t)(2 * kDirectBands)) ? kDirectBands : 1;
+		uint32_t tickets[kDirectBands];
+		size_t band_y1[kDirectBands];
+		for (int b = 0; b < bands; b++) {
+			const size_t r0 = (size_t)b * hb / (size_t)bands, r1 = (size_t)(b + 1) * hb / (size_t)bands;
+			band_y1[b] = b + 1 == bands ? height : (r1 * 4u < height ? r1 * 4u : height);
+			tickets[b] = next_ticket(c);
+			bool empty = false;
+			if (!launch_rows(epi, x.d_base + x.in_off, x.d_base + x.out_off, d_st, r0, r1,
+					Completion{ reinterpret_cast<uint32_t *>(x.d_base + (bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)), c.d_status + 16 + b, tickets[b] }, &empty)) return kFalse;
+			if (empty) tickets[b] = 0;
+		}
+		size_t y_done = 0;
+		for (int b = 0; b < bands; b++) {
+			if (tickets[b] != 0 && !wait_for_ticket(c, x, tickets[b], bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)) return kFalse;
+			copy_out_rows(x.h_base + x.out_off, y_done, band_y1[b]);
+			y_done = band_y1[b];
+		}
+		return *h_status != 0 ? block_failed() : kTrue;
+	}
+
+	// Larger textures: staged through device memory.  Per call (measured piece by piece, tools/ubench/host_midsize.hip): the status word
+	// is NOT zeroed by a memset (the device word is zero between calls: a call that raised it zeroes it again afterwards), it is read from
+	// PINNED memory (a 4-byte copy into pageable memory costs 25 us, into pinned memory 13, none at all for up to 2^20 blocks: below), and
+	// blocks of up to Tune::kHostPinnedInputBytes reach the kernel through the pinned buffer, read across the link as it decodes (a memcpy
+	// of 512 KiB: 4 us; the runtime's copy out of pageable memory: 27).  The pixels travel by the runtime's device-to-host copy into the
+	// caller's pageable buffer: at these sizes it pins the pages and runs at the link's rate, which no copy loop of one host thread reaches.
+	// (upload -> one launch -> download on the thread's stream; the PCIe download of the pixels bounds it: 8192^2 BC1 256 MiB at 55 GB/s =
+	// 4.8 ms, upload 0.6 ms, kernel 0.04 ms.  A band pipeline -- upload k+1 | kernel k | download k-1 on three streams -- was built and
+	// measured in round 2: 5.40 vs 5.45 ms, a download that shares the link with an upload runs at 41-50 GB/s; two bands on two streams
+	// at 1024^2 in round 5: 135 vs 121 us.  Neither was kept.)
+	Outcome via_staging() const {
+		const bool pinned_in = in_bytes <= Tune::kHostPinnedInputBytes;
+		DirectExchange x;
+		if (!direct_exchange(c, pinned_in ? in_bytes : 0, 0, &x)) return kFalse;
+		if (!reserve(&c.d_out, &c.out_cap, out_bytes) || (!pinned_in && !reserve(&c.d_in, &c.in_cap, in_bytes))) return kFalse;
+		uint8_t *d_out = static_cast<uint8_t *>(c.d_out);
+		const uint8_t *d_in;
+		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
+		if (pinned_in) {
+			memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+			d_in = x.d_base + x.in_off;
+		} else {
+			if (!try_hip(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)")) return kFalse;
+			d_in = static_cast<const uint8_t *>(c.d_in);
+		}
+		// The status word: up to 2^20 blocks it lives in the pinned header itself -- only a wave that holds a failed block touches it (one
+		// load, at most one store across the link), and the call saves the copy that would fetch it (13 us); beyond that (tens of thousands
+		// of waves may hold a failed block of a random stream) it stays in device memory and is fetched into the pinned word.
+		const bool pinned_status = wb * hb <= ((size_t)1 << 20);
+		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
+		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
+		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
+		const int rc = tiled ? detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status)
+			: detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format, c.stream, d_status);
+		if (rc != 0) return kFalse;
+		if (tiled || (cov_w == width && cov_h == height)) {
+			if (!try_hip(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
+		} else if (cov_w > 0 && cov_h > 0) {
+			if (!try_hip(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)")) return kFalse;
+		}
+		if (!pinned_status && !try_hip(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
+		if (!try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
+		if (*h_status == 0) return kTrue;
+		if (!pinned_status) {		// (the device word is zero between calls: restore that before reporting)
+			if (!try_hip(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync") || !try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
+		}
+		return block_failed();
+	}
+};
+
+// shared body of the two texture drivers (texture.c:77-98, 105-145): argument checks and the reference's non-decode edges here, the
+// decode in TextureCall above
 static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffer, uint32_t pixel_format, bool tiled) {
 	const char *who = tiled ? "detexDecompressTextureTiled" : "detexDecompressTextureLinear";
 	const size_t px = (size_t)detexGetPixelSize(pixel_format);
@@ -303,200 +485,17 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
 	const size_t bs = detexGetCompressedBlockSize(texture->format);
-	const size_t in_bytes = wb * hb * bs;
-	// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
-	// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
-	const size_t cov_w = tiled ? 0 : (width < 4u * wb ? width : 4u * wb), cov_h = tiled ? 0 : (height < 4u * hb ? height : 4u * hb);
-	auto copy_out = [&](const uint8_t *res) {
-		if (tiled || (cov_w == width && cov_h == height)) memcpy(pixel_buffer, res, out_bytes);
-		else for (size_t y = 0; y < cov_h; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
-	};
-	auto copy_out_rows = [&](const uint8_t *res, size_t y0, size_t y1) {		// linear layout: image rows [y0, y1)
-		if (y1 > cov_h) y1 = cov_h;
-		if (y0 >= y1) return;
-		if (cov_w == width) memcpy(pixel_buffer + y0 * width * px, res + y0 * width * px, (y1 - y0) * width * px);
-		else for (size_t y = y0; y < y1; y++) memcpy(pixel_buffer + y * width * px, res + y * width * px, cov_w * px);
-	};
-	// Linear textures with a quarter MiB to Tune::kHostRegisterOutputBytes (2 MiB) of pixels: the CALLER's pixel buffer is registered with the
-	// runtime for the duration of the call and the kernel writes straight into it -- no staging buffer on either side of the link, no copy
-	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate at these sizes (1 MiB: 19 us of
-	// data, 4 MiB: 87 vs 84), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of
-	// freshly written pinned memory -- cost more: 512^2 50.5 -> 41.1 us, BC7 56.7 -> 45.7 (same-run A/B from compiled C,
-	// profiles/r05/host_registered_output_ab.txt).  At 4 MiB the staged path's DMA download is as fast (1024^2: 120.5 vs 118.5), beyond
-	// that faster (16 MiB: 391 vs 305 us of data): the window ends at 2 MiB.  The kernel writes exactly the pixels the reference would
-	// (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the caller, sharing a page with
-	// another thread's registered buffer) takes the paths below.
-	if (!tiled && out_bytes > ((size_t)256 << 10) && out_bytes <= Tune::kHostRegisterOutputBytes && in_bytes <= Tune::kHostPinnedInputBytes) {
-		struct Registered {		// (unregistered on every way out)
-			void *host = nullptr, *dev = nullptr;
-			Registered(void *p, size_t n) {
-				if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
-				host = p;
-				if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
-			}
-			~Registered() { if (host) (void)hipHostUnregister(host); }
-		} reg(pixel_buffer, out_bytes);
-		const int epi = reg.dev ? prepared_epilogue(texture->format, pixel_format) : -1;
-		if (epi == -2) return false;
-		DirectExchange x;
-		if (reg.dev && epi >= 0 && direct_exchange(c, in_bytes, 0, &x)) {
-			(void)c.service.wanted(nullptr, -1);		// a larger call ends a row of small ones
-			memcpy(x.h_base + x.in_off, texture->data, in_bytes);
-			*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
-			const uint32_t ticket = next_ticket(c);
-			LevelsArgs a{};
-			a.status = reinterpret_cast<uint32_t *>(x.d_base); a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
-			a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket };
-			a.table.n_levels = 1;
-			LevelDesc &lv = a.table.level[0];
-			lv.blocks = x.d_base + x.in_off; lv.pixels = static_cast<uint8_t *>(reg.dev); lv.pitch = width * px;
-			lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * hb); lv.width = (uint32_t)width; lv.height = (uint32_t)height;
-			a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
-			HIP_TRY(f->levels(a), "kernel launch");
-			if (!wait_for_ticket(c, x, ticket)) return false;
-			if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
-				detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-				return false;
-			}
-			return true;
-		}
-	}
-	if (in_bytes + out_bytes <= Tune::kHostDirectBytes) {
-		// the smallest textures (either layout), from the second call in a row on: a request to the resident kernel instead of a launch
-		if (wb * hb <= kResidentMaxBlocks && in_bytes <= kResidentBlockBytes && out_bytes <= kResidentPixelBytes) {
-			const int epi = prepared_epilogue(texture->format, pixel_format);
-			if (epi == -2) return false;
-			if (c.service.wanted(f, epi)) {
-				// (up to one tile: the blocks travel as tagged chunks the kernel reads along with its polls -- path_types.h: kResidentTagged)
-				const bool tagged = wb * hb <= 256u;
-				const uint32_t payload[12] = { (uint32_t)width, (uint32_t)height, (uint32_t)wb, (uint32_t)hb, 0xFFFFFFFFu, current_spec_flags(),
-					tagged ? kResidentTagged : kResidentTexture, tiled ? 1u : 0u };
-				bool failed = false;
-				const uint32_t number = c.service.begin(f, epi);
-				if (number != 0u) {
-					if (tagged) c.service.pack_tagged(texture->data, in_bytes, number);
-					else memcpy(c.service.blocks_host(), texture->data, in_bytes);
-				}
-				if (number != 0u && c.service.serve(payload, number, &failed)) {
-					copy_out(c.service.pixels_host());
-					if (failed) detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-					return !failed;
-				}
-			}
-		} else {
-			(void)c.service.wanted(nullptr, -1);		// a larger call ends the row
-		}
-		// small texture: the kernel reads the blocks from, and writes pixels and status into, pinned host memory (direct_exchange)
-		DirectExchange x;
-		if (!direct_exchange(c, in_bytes, out_bytes, &x)) return false;
-		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
-		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
-		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
-		if (tiled) {
-			if (detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st) != 0) return false;
-			HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-		} else {
-			// the one-level form of the mip-chain kernel (any geometry in one launch), which publishes the completion word
-			const int epi = prepared_epilogue(texture->format, pixel_format);
-			if (epi == -2) return false;
-			// Above a quarter MiB of pixels the call is made in kDirectBands bands of block rows (a band is one contiguous range of blocks
-			// and of image rows, texture.c:115-141), one launch and one completion word each, all launched at once: the caller copies band
-			// k out of the pinned buffer while the kernels of the later bands are still writing theirs across the link -- the copy-out of
-			// freshly written pinned memory runs at ~20 GB/s on one host thread, half the link's rate, and was a third of a 512x512 call.
-			const int bands = (out_bytes > ((size_t)256 << 10) && hb >= (size_t)(2 * kDirectBands)) ? kDirectBands : 1;
-			uint32_t tickets[kDirectBands];
-			size_t band_y1[kDirectBands];
-			for (int b = 0; b < bands; b++) {
-				const size_t r0 = (size_t)b * hb / (size_t)bands, r1 = (size_t)(b + 1) * hb / (size_t)bands;
-				const size_t y0 = r0 * 4u < height ? r0 * 4u : height, y1 = r1 * 4u < height ? r1 * 4u : height;
-				band_y1[b] = b + 1 == bands ? height : y1;
-				tickets[b] = next_ticket(c);
-				LevelsArgs a{};
-				a.status = d_st; a.stream = c.stream; a.epi = epi; a.decode_flags = current_spec_flags();
-				a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + (bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)), c.d_status + 16 + b, tickets[b] };
-				a.table.n_levels = 1;
-				LevelDesc &lv = a.table.level[0];
-				lv.blocks = x.d_base + x.in_off + r0 * wb * bs; lv.pixels = x.d_base + x.out_off + y0 * width * px; lv.pitch = width * px;
-				lv.width_in_blocks = (uint32_t)wb; lv.n_blocks = (uint32_t)(wb * (r1 - r0)); lv.width = (uint32_t)width; lv.height = (uint32_t)(y1 - y0);
-				a.table.wg_start[0] = 0; a.table.wg_start[1] = (lv.n_blocks + 255u) / 256u;
-				if (lv.n_blocks == 0 || y1 == y0) { tickets[b] = 0; continue; }		// (rows of blocks below the image: nothing to decode)
-				HIP_TRY(f->levels(a), "kernel launch");
-			}
-			if (bands == 1) {
-				if (!wait_for_ticket(c, x, tickets[0])) return false;
-			} else {
-				size_t y_done = 0;
-				for (int b = 0; b < bands; b++) {
-					if (tickets[b] != 0 && !wait_for_ticket(c, x, tickets[b], kBandDoneOffset + 16u * (size_t)b)) return false;
-					copy_out_rows(x.h_base + x.out_off, y_done, band_y1[b]);
-					y_done = band_y1[b];
-				}
-				if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
-					detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-					return false;
-				}
-				return true;
-			}
-		}
-		copy_out(x.h_base + x.out_off);
-		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) {
-			detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-			return false;
-		}
-		return true;
-	}
-	// Larger textures: staged through device memory.  Per call (measured piece by piece, tools/ubench/host_midsize.hip): the status word
-	// is NOT zeroed by a memset (the device word is zero between calls: a call that raised it zeroes it again afterwards), it is read from
-	// PINNED memory (a 4-byte copy into pageable memory costs 25 us, into pinned memory 13, none at all for up to 2^20 blocks: below), and
-	// blocks of up to Tune::kHostPinnedInputBytes reach
-	// the kernel through the pinned buffer, read across the link as it decodes (a memcpy of 512 KiB: 4 us; the runtime's copy out of
-	// pageable memory: 27).  The pixels travel by the runtime's device-to-host copy into the caller's pageable buffer: at these sizes it
-	// pins the pages and runs at the link's rate, which no copy loop of one host thread reaches.
-	const bool pinned_in = in_bytes <= Tune::kHostPinnedInputBytes;
-	DirectExchange x;
-	if (!direct_exchange(c, pinned_in ? in_bytes : 0, 0, &x)) return false;
-	if (!reserve(&c.d_out, &c.out_cap, out_bytes) || (!pinned_in && !reserve(&c.d_in, &c.in_cap, in_bytes))) return false;
-	uint8_t *d_out = static_cast<uint8_t *>(c.d_out);
-	const uint8_t *d_in;
-	if (pinned_in) {
-		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
-		d_in = x.d_base + x.in_off;
-	} else {
-		HIP_TRY(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
-		d_in = static_cast<const uint8_t *>(c.d_in);
-	}
-	// The status word: up to 2^20 blocks it lives in the pinned header itself -- only a wave that holds a failed block touches it (one
-	// load, at most one store across the link), and the call saves the copy that would fetch it (13 us); beyond that (tens of thousands
-	// of waves may hold a failed block of a random stream) it stays in device memory and is fetched into the pinned word.
-	const bool pinned_status = wb * hb <= ((size_t)1 << 20);
-	volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
-	uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
-	*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
-	int rc;
-	if (tiled)
-		rc = detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status);
-	else
-		rc = detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format,
-			c.stream, d_status);
-	if (rc != 0) return false;
-	if (tiled || (cov_w == width && cov_h == height)) {
-		HIP_TRY(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
-	} else if (cov_w > 0 && cov_h > 0) {
-		HIP_TRY(hipMemcpy2DAsync(pixel_buffer, width * px, d_out, width * px, cov_w * px, cov_h, hipMemcpyDeviceToHost, c.stream), "hipMemcpy2DAsync(D2H)");
-	}
-	if (!pinned_status) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
-	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-	const uint32_t status = *h_status;
-	if (status != 0) {
-		if (!pinned_status) {		// (the device word is zero between calls: restore that before reporting)
-			HIP_TRY(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync");
-			HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-		}
-		// same text the reference leaves behind after a failed block (texture.c:63-64)
-		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", texture->format);
-		return false;
-	}
-	return true;
+	TextureCall call{ c, f, texture, pixel_buffer, pixel_format, tiled, px, wb, hb, width, height, bs, wb * hb * bs, out_bytes,
+		// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
+		// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
+		tiled ? 0 : (width < 4u * wb ? width : 4u * wb), tiled ? 0 : (height < 4u * hb ? height : 4u * hb) };
+	// by size: the resident service (up to 1024 blocks, from the second call in a row on), the caller's buffer registered for the call
+	// (linear, 1/4 - 2 MiB of pixels), the pinned exchange (up to 1.25 MiB in all), staging through device memory
+	Outcome r = call.via_resident_service();
+	if (r == kNotTaken) r = call.via_registered_output();
+	if (r == kNotTaken) r = call.via_pinned_exchange();
+	if (r == kNotTaken) r = call.via_staging();
+	return r == kTrue;
 }
 
 // 8f-3 host tier: what a caller of detexLoadKTXFileWithMipmaps does level by level (one
