@@ -320,44 +320,9 @@ struct TextureCall {
 		return failed ? block_failed() : kTrue;
 	}
 
-	// Linear textures with a quarter MiB to Tune::kHostRegisterOutputBytes (2 MiB) of pixels: the CALLER's pixel buffer is registered with the
-	// runtime for the duration of the call and the kernel writes straight into it -- no staging buffer on either side of the link, no copy
-	// command, no copy-out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate at these sizes (1 MiB: 19 us of
-	// data, 4 MiB: 87 vs 84), registering and unregistering cost ~10 us together, and what it replaces -- the pinned exchange's copy-out of
-	// freshly written pinned memory -- cost more: 512^2 50.5 -> 41.1 us, BC7 56.7 -> 45.7 (same-run A/B from compiled C,
-	// profiles/r05/host_registered_output_ab.txt).  At 4 MiB the staged path's DMA download is as fast (1024^2: 120.5 vs 118.5), beyond
-	// that faster (16 MiB: 391 vs 305 us of data): the window ends at 2 MiB.  The kernel writes exactly the pixels the reference would
-	// (clipping, a grid smaller than the image); a buffer that cannot be registered (already registered by the caller, sharing a page with
-	// another thread's registered buffer) takes the paths below.
-	Outcome via_registered_output() const {
-		if (tiled || out_bytes <= ((size_t)256 << 10) || out_bytes > Tune::kHostRegisterOutputBytes || in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
-		struct Registered {		// (unregistered on every way out)
-			void *host = nullptr, *dev = nullptr;
-			Registered(void *p, size_t n) {
-				if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
-				host = p;
-				if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
-			}
-			~Registered() { if (host) (void)hipHostUnregister(host); }
-		} reg(pixel_buffer, out_bytes);
-		if (!reg.dev) return kNotTaken;
-		const int epi = prepared_epilogue(texture->format, pixel_format);
-		if (epi == -2) return kFalse;
-		DirectExchange x;
-		if (!direct_exchange(c, in_bytes, 0, &x)) return kFalse;
-		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
-		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
-		const uint32_t ticket = next_ticket(c);
-		bool empty = false;
-		if (!launch_rows(epi, x.d_base + x.in_off, static_cast<uint8_t *>(reg.dev), reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
-				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket }, &empty)) return kFalse;
-		if (!empty && !wait_for_ticket(c, x, ticket)) return kFalse;
-		return *reinterpret_cast<volatile uint32_t *>(x.h_base) != 0 ? block_failed() : kTrue;
-	}
-
 	// Blocks + pixels up to Tune::kHostDirectBytes: the kernel reads the blocks from, and writes pixels and status into, pinned host memory
-	// (direct_exchange); the caller polls a completion word and copies the pixels out.  Above a quarter MiB of pixels (a buffer the path
-	// above could not register) the linear layout goes in kDirectBands bands of block rows -- a band is one contiguous range of blocks and
+	// (direct_exchange); the caller polls a completion word and copies the pixels out.  Above a quarter MiB of pixels the linear layout
+	// goes in kDirectBands bands of block rows -- a band is one contiguous range of blocks and
 	// of image rows, texture.c:115-141 -- one launch and one completion word each, all launched at once: band k is copied out while the
 	// kernels of the later bands are still writing theirs across the link (the copy-out of freshly written pinned memory runs at ~20 GB/s
 	// on one host thread, half the link's rate).
@@ -489,10 +454,12 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
 		// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
 		tiled ? 0 : (width < 4u * wb ? width : 4u * wb), tiled ? 0 : (height < 4u * hb ? height : 4u * hb) };
-	// by size: the resident service (up to 1024 blocks, from the second call in a row on), the caller's buffer registered for the call
-	// (linear, 1/4 - 2 MiB of pixels), the pinned exchange (up to 1.25 MiB in all), staging through device memory
+	// by size: the resident service (up to 1024 blocks, from the second call in a row on), the pinned exchange (up to 1.25 MiB in all),
+	// staging through device memory.  (Round 5 also built a fourth path -- the caller's pixel buffer registered with the runtime for the call,
+	// the kernel writing straight into it: 512^2 50.5 -> 41.1 us -- and took it out again: one full test run of five ended in a GPU memory
+	// access fault at a host heap address during a LATER, unrelated copy of the same process.  Registering memory the library does not own,
+	// which its owner then frees, is not something this tier can make safe: profiles/r05/host_registered_output_fault.txt.)
 	Outcome r = call.via_resident_service();
-	if (r == kNotTaken) r = call.via_registered_output();
 	if (r == kNotTaken) r = call.via_pinned_exchange();
 	if (r == kNotTaken) r = call.via_staging();
 	return r == kTrue;

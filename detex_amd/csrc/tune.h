@@ -50,9 +50,6 @@ struct ProductTune {
 	// ... and larger textures whose BLOCKS fit in this many bytes hand them over through the same pinned buffer (read by the kernel across
 	// the link) instead of an upload out of pageable memory; 0 = always upload
 	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
-	// ... and linear textures with more than a quarter MiB and up to this many bytes of PIXELS are written by the kernel straight into the
-	// caller's buffer, registered for the call (0 = never)
-	static constexpr unsigned long kHostRegisterOutputBytes = 2ul << 20;
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };

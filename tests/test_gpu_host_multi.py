@@ -332,12 +332,13 @@ def test_host_tier_status_does_not_leak_between_calls(W, H, hiplib, oracle):
             assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
 
 
-# ---- mid-size textures: the kernel writes straight into the caller's buffer, registered for the call (host_tier.cpp) ---------------------
+# ---- mid-size textures (0.25 - 2 MiB of pixels): the banded pinned exchange and the lower end of the staged path (host_tier.cpp) -------------
 @pytest.mark.parametrize("name,W,H,wb,hb", [("BC1", 512, 512, None, None), ("BPTC", 724, 724, None, None), ("BPTC", 701, 333, None, None), ("BC3", 1001, 513, None, None),
                                             ("RGTC1", 2048, 1024, None, None), ("BPTC_FLOAT", 512, 384, None, None), ("ETC2", 900, 400, 200, 90), ("EAC_RG11", 1022, 258, None, None)])
-def test_host_tier_registered_output_window(name, W, H, wb, hb, hiplib, oracle):
-    """0.25-2 MiB of pixels (724^2 and 2048x1024 R8 sit at the window's upper edge): whole and clipped sizes, a block grid smaller than the image (the rest of the caller's buffer must survive),
-    invalid blocks (zero-filled, false + the reference's text), 64-bit pixels, narrow pixels -- twice each (registration is per call)"""
+def test_host_tier_mid_size_window(name, W, H, wb, hb, hiplib, oracle):
+    """0.25-2 MiB of pixels, both sides of the pinned exchange's 1.25 MiB limit: whole and clipped sizes, a block grid smaller than the image
+    (the rest of the caller's buffer must survive), invalid blocks (zero-filled, false + the reference's text), 64-bit pixels, narrow
+    pixels -- twice each"""
     fmt = F.BY_NAME[name]
     gwb, ghb = (W + 3) // 4 if wb is None else wb, (H + 3) // 4 if hb is None else hb
     data = ol.stream_u(fmt, gwb * ghb, seed=0x4E6 + fmt.index + W)
@@ -357,9 +358,9 @@ def test_host_tier_registered_output_window(name, W, H, wb, hb, hiplib, oracle):
             assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
 
 
-def test_host_tier_registered_output_fallbacks(hiplib, oracle, torch_cuda):
-    """buffers the library cannot register for itself -- already pinned by the caller (a torch pinned tensor), or sharing pages with a buffer
-    another thread's call has registered at that moment -- and a pixel pointer that is not 16-byte aligned: the result is the same"""
+def test_host_tier_unusual_caller_buffers(hiplib, oracle, torch_cuda):
+    """a pixel buffer that is pinned by the caller (a torch pinned tensor), one that is not 16-byte aligned, and four threads decoding into
+    adjacent images inside one allocation (neighbours share a page at every boundary): the result is the same"""
     import threading
     torch = torch_cuda
     fmt = F.BY_NAME["BC1"]

@@ -18,7 +18,6 @@
 #   sgprconst               v_bitop3 masks left in SGPRs
 #   rgtc1gN                 RGTC1 blocks per lane
 #   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
-#   hostregisterN           host tier: pixels of up to N bytes are written straight into the caller's buffer, registered for the call (0 = never)
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
 #   wgN                     N resident workgroups per CU for every linear kernel (0 = no cap; default: the per-format table)
 #   sleepN                  s_sleep N between a wave's row stores (linear kernels)
@@ -53,7 +52,6 @@ for v in "$@"; do
       sgprconst) body+="static constexpr bool kMasksInVgprs = false; " ;;
       rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
       hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
-      hostregister*) body+="static constexpr unsigned long kHostRegisterOutputBytes = ${k#hostregister}; " ;;
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
       wg*) body+="static constexpr int kWorkgroupsPerCu = ${k#wg}; " ;;
       sleep*) body+="static constexpr int kStoreSleep = ${k#sleep}; " ;;
