@@ -456,7 +456,7 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		tiled ? 0 : (width < 4u * wb ? width : 4u * wb), tiled ? 0 : (height < 4u * hb ? height : 4u * hb) };
 	// by size: the resident service (up to 1024 blocks, from the second call in a row on), the pinned exchange (up to 1.25 MiB in all),
 	// staging through device memory.  (Round 5 also built a fourth path -- the caller's pixel buffer registered with the runtime for the call,
-	// the kernel writing straight into it: 512^2 50.5 -> 41.1 us -- and took it out again: one full test run of five ended in a GPU memory
+	// the kernel writing straight into it: 512^2 50.5 -> 41.1 us -- and took it out again: the third full test run with it ended in a GPU memory
 	// access fault at a host heap address during a LATER, unrelated copy of the same process.  Registering memory the library does not own,
 	// which its owner then frees, is not something this tier can make safe: profiles/r05/host_registered_output_fault.txt.)
 	Outcome r = call.via_resident_service();
