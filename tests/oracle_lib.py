@@ -40,8 +40,10 @@ class Oracle:
         ok = self.lib.orc_decode_block(fmt.index, _ptr(data), mode_mask, flags, _ptr(out))
         return bool(ok), out
 
-    def linear(self, fmt, data, width, height):
-        wb, hb = (width + 3) // 4, (height + 3) // 4
+    def linear(self, fmt, data, width, height, wb=None, hb=None):
+        """wb, hb: the texture's block grid where it is not the image's (texture.c:105-145 loops over the grid and clips to the image)"""
+        wb = (width + 3) // 4 if wb is None else wb
+        hb = (height + 3) // 4 if hb is None else hb
         data = np.ascontiguousarray(data, dtype=np.uint8)
         assert data.size >= wb * hb * fmt.block_bytes
         out = np.zeros(width * height * fmt.pixel_bytes, np.uint8)

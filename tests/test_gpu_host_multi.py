@@ -397,3 +397,29 @@ def test_host_tier_unusual_caller_buffers(hiplib, oracle, torch_cuda):
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("W,H,wb,hb", [(512, 300, 128, 128), (304, 64, 76, 40), (1024, 1024, 256, 300), (64, 20, 16, 9)])
+def test_block_grid_taller_than_the_image(W, H, wb, hb, hiplib, oracle, ref):
+    """a block grid that reaches below the image (height < 4 * height_in_blocks by more than a block row): the reference decodes every block of
+    the grid, stores only what lies inside the image, and returns false if ANY block of the grid is invalid (texture.c:112-144) -- through
+    the resident service, the banded pinned exchange and the staged path alike.  (A grid WIDER than the image by more than a block makes the
+    reference itself copy a negative number of bytes: outside its contract, not tested.)"""
+    fmt = F.BY_NAME["BPTC"]
+    data = ol.stream_u(fmt, wb * hb, seed=0x7A11 + W)
+    blk = data.reshape(-1, 16)
+    blk[:, 0] |= 1                                   # every block valid ...
+    ok_all, want = oracle.linear(fmt, data, W, H, wb=wb, hb=hb)
+    assert ok_all
+    if ref is not None:
+        ok_r, want_r = ref.linear(fmt, data, W, H, wb=wb, hb=hb)
+        assert ok_r and np.array_equal(want_r, want)
+    for rep in range(2):
+        ok, got = hiplib.linear(fmt, data, W, H, wb=wb, hb=hb)
+        assert ok and np.array_equal(got, want), (W, H, rep)
+    blk[(hb - 1) * wb + 3, :] = 0                     # ... except one in the LAST block row, which lies wholly below the image
+    ok_bad, want_bad = oracle.linear(fmt, data, W, H, wb=wb, hb=hb)
+    assert not ok_bad and np.array_equal(want_bad, want)
+    for rep in range(2):
+        ok, got = hiplib.linear(fmt, data, W, H, wb=wb, hb=hb)
+        assert not ok and np.array_equal(got, want), (W, H, rep)
