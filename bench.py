@@ -217,6 +217,33 @@ def live_pmc_traffic(fmt_name, side, layout="linear", timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+MALL_BYTES = 256 << 20                 # Infinity Cache (MI355X_MICROARCH.md): a footprint that fits is served from it, not from HBM
+
+
+def roofline_row(alg_bytes, write_bytes, pixels, launch_us):
+    """One row of the per-format tables from a launch time.  `frac` = algorithmic bytes / time / 8 TB/s -- but null where that is not an HBM
+    fraction: a footprint (blocks + pixels) that fits the 256 MiB Infinity Cache, or a rate above the peak.  `write_frac` = pixels written /
+    time / 8 TB/s (north_star's "HBM-write roofline"), which no cache inflates at sizes whose pixels do not fit it."""
+    ach = alg_bytes / (launch_us * 1e-6) / 1e9
+    resident = bool(alg_bytes <= MALL_BYTES)
+    row = {"launch_us": round(launch_us, 2), "gpixel_s": round(pixels / (launch_us * 1e-6) / 1e9, 1),
+           "achieved_GBps": round(ach, 1), "frac": None if resident else round(ach / HBM_PEAK_GBPS, 4),
+           "footprint_MiB": round(alg_bytes / 2 ** 20, 1), "cache_resident": resident}
+    if resident:
+        row["frac_note"] = ("blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s) and no roofline fraction is given; "
+                            "per_format.beyond_cache_16384 has this format at a size that does not fit")
+    row["write_frac"] = None if resident else round(write_bytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+    if not resident and ach > HBM_PEAK_GBPS:
+        # (coherent content -- stream C -- in the cheapest decoders at 16384^2: 8.0-8.25 TB/s at the L2's memory interface, where the PMC counters see
+        # exactly the algorithmic bytes for stream C as for stream U: profiles/r05/stream_c_16384_counters.jsonl.  The 128-256 MiB of BLOCKS
+        # can be served by the Infinity Cache behind that interface from launch to launch, and the pins' rate is 8.19 TB/s, not the guide's
+        # round 8: a rate above the peak is not an HBM rate, so no fraction is claimed -- write_frac stands)
+        row["frac"] = None
+        row["frac_note"] = ("above the 8 TB/s peak: the blocks of this size (<= 256 MiB) can be served by the Infinity Cache behind the L2's memory interface; "
+                            "no HBM fraction is given, write_frac is the cache-proof figure")
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,30 +429,10 @@ def main():
             prev = us
         return us, done
 
-    MALL_BYTES = 256 << 20                 # Infinity Cache (MI355X_MICROARCH.md): a footprint that fits is served from it, not from HBM
     telemetry = Telemetry(torch, device_index)
 
     def roofline_of(job, launch_us, clocks=True):
-        ach = job.alg_bytes / (launch_us * 1e-6) / 1e9
-        resident = bool(job.alg_bytes <= MALL_BYTES)
-        # (a footprint that fits the Infinity Cache is not served from HBM: no HBM fraction is claimed for it -- frac is null, the rate stays)
-        row = {"launch_us": round(launch_us, 2), "gpixel_s": round(job.W * job.H / (launch_us * 1e-6) / 1e9, 1),
-               "achieved_GBps": round(ach, 1), "frac": None if resident else round(ach / HBM_PEAK_GBPS, 4),
-               "footprint_MiB": round(job.alg_bytes / 2 ** 20, 1), "cache_resident": resident}
-        if resident:
-            row["frac_note"] = ("blocks + pixels fit the 256 MiB Infinity Cache: the rate is not an HBM rate (it may exceed 8 TB/s) and no roofline fraction is given; "
-                                "per_format.beyond_cache_16384 has this format at a size that does not fit")
-        # the write-only fraction (north_star's "HBM-write roofline"): pixels written / time / 8 TB/s -- a lower bound that no cache can inflate
-        # at sizes whose PIXELS do not fit the Infinity Cache
-        row["write_frac"] = None if resident else round(job.blocks * 16 * job.tpx / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
-        if not resident and ach > HBM_PEAK_GBPS:
-            # (coherent content -- stream C -- in the cheapest decoders at 16384^2: 8.0-8.25 TB/s at the L2's memory interface, where the PMC counters see
-            # exactly the algorithmic bytes for stream C as for stream U: profiles/r05/stream_c_16384_counters.jsonl.  The 128-256 MiB of BLOCKS
-            # can be served by the Infinity Cache behind that interface from launch to launch, and the pins' rate is 8.19 TB/s, not the guide's
-            # round 8: a rate above the peak is not an HBM rate, so no fraction is claimed -- write_frac stands)
-            row["frac"] = None
-            row["frac_note"] = ("above the 8 TB/s peak: the blocks of this size (<= 256 MiB) can be served by the Infinity Cache behind the L2's memory interface; "
-                                "no HBM fraction is given, write_frac is the cache-proof figure")
+        row = roofline_row(job.alg_bytes, job.blocks * 16 * job.tpx, job.W * job.H, launch_us)
         if clocks:                         # shader clock and board power while this kernel runs back to back (0.15 s, hwmon files)
             t = telemetry.during(job.step)
             torch.cuda.synchronize()

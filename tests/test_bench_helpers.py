@@ -56,3 +56,19 @@ def test_band_goldens_cover_every_world_size_the_bench_checks():
     for g in range(4):                                                   # a quarter band (north_star: BC1 over 4 GPUs) = two eighths
         q = gold["BC1/32768/%dof4" % g]
         assert q["bytes"] == 2 * gold["BC1/32768/0of8"]["bytes"] and q["row0"] == gold["BC1/32768/%dof8" % (2 * g)]["row0"]
+
+
+def test_roofline_rows_claim_no_fraction_where_it_would_not_be_an_hbm_fraction(bench):
+    """`frac` is null for a footprint that fits the 256 MiB Infinity Cache and for a rate above the 8 TB/s peak (no
+    fraction above 1 anywhere); `write_frac` is given wherever the footprint exceeds the cache"""
+    blocks = 2048 * 2048
+    bc1 = bench.roofline_row(blocks * 72, blocks * 64, 8192 * 8192, 41.3)                  # 288 MiB: beyond the cache
+    assert bc1["cache_resident"] is False and abs(bc1["frac"] - 0.914) < 0.002 and abs(bc1["write_frac"] - 0.8125) < 0.002 and "frac_note" not in bc1
+    rgtc1 = bench.roofline_row(blocks * 24, blocks * 16, 8192 * 8192, 11.9)                # 96 MiB, 8.5 TB/s: cache-resident
+    assert rgtc1["cache_resident"] is True and rgtc1["frac"] is None and rgtc1["write_frac"] is None and rgtc1["achieved_GBps"] > 8000
+    pt = bench.roofline_row(4 * blocks * 72, 4 * blocks * 64, 16384 * 16384, 146.4)        # 1152 MiB at 8.25 TB/s: above the peak
+    assert pt["cache_resident"] is False and pt["frac"] is None and 0.9 < pt["write_frac"] < 1.0 and "above the 8 TB/s peak" in pt["frac_note"]
+    for launch_us in (10.0, 40.0, 160.0, 640.0):
+        for scale in (1, 4):
+            row = bench.roofline_row(scale * blocks * 80, scale * blocks * 64, scale * 8192 * 8192, launch_us)
+            assert row["frac"] is None or row["frac"] <= 1.0
