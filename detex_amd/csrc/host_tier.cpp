@@ -4,6 +4,8 @@
 // fail with an error message.  Host code only.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "host_internal.h"
 #include "tune.h"
@@ -11,6 +13,23 @@
 using namespace detexhip;
 
 namespace {
+
+// ---- pixel buffers owned by the library (detexhipAllocPixelBuffer) ------------------------------------------------------------------------
+// Pinned, device-visible host memory handed to the caller to be used as the pixel_buffer of the texture drivers: a kernel can write straight
+// into it (no staging buffer on the host side of the link, no copy-out -- what the removed registered-output path did with memory the
+// library did NOT own).  Process-wide registry, a handful of entries; looked up per call under a mutex (tens of nanoseconds).
+struct OwnedBuffer { uint8_t *host, *dev; size_t bytes; };
+std::mutex g_owned_mutex;
+std::vector<OwnedBuffer> g_owned;
+// device view of [p, p + n) if that range lies inside one owned buffer
+uint8_t *owned_device_view(const void *p, size_t n) {
+	const uint8_t *q = static_cast<const uint8_t *>(p);
+	std::lock_guard<std::mutex> lock(g_owned_mutex);
+	for (const OwnedBuffer &b : g_owned)
+		if (q >= b.host && n <= b.bytes && (size_t)(q - b.host) <= b.bytes - n) return b.dev + (q - b.host);
+	return nullptr;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // per-thread device context of the host-pointer tier: a stream and grow-only device staging buffers that
@@ -206,6 +225,33 @@ namespace detexhip {
 void release_thread_context() { t_ctx.release(); }
 }
 
+// Pixel buffers the kernels can write into directly (include/detexhip.h).  Portable pinned memory: visible to every device.
+extern "C" void *detexhipAllocPixelBuffer(size_t bytes) {
+	if (bytes == 0) bytes = 16;
+	void *h = nullptr, *d = nullptr;
+	hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocPortable);
+	if (e != hipSuccess) { (void)hipGetLastError(); detexSetErrorMessage("detexhipAllocPixelBuffer: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+	if ((e = hipHostGetDevicePointer(&d, h, 0)) != hipSuccess) {
+		(void)hipGetLastError(); (void)hipHostFree(h);
+		detexSetErrorMessage("detexhipAllocPixelBuffer: hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+		return nullptr;
+	}
+	std::lock_guard<std::mutex> lock(g_owned_mutex);
+	g_owned.push_back(OwnedBuffer{ static_cast<uint8_t *>(h), static_cast<uint8_t *>(d), bytes });
+	return h;
+}
+extern "C" void detexhipFreePixelBuffer(void *p) {
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lock(g_owned_mutex);
+		size_t k = 0;
+		while (k < g_owned.size() && g_owned[k].host != p) k++;
+		if (k == g_owned.size()) { detexSetErrorMessage("detexhipFreePixelBuffer: %p was not returned by detexhipAllocPixelBuffer", p); return; }
+		g_owned.erase(g_owned.begin() + (long)k);
+	}
+	(void)hipHostFree(p);
+}
+
 extern "C" void detexhipGetResidentStats(unsigned long long *requests, unsigned long long *instances) {
 	if (requests) *requests = t_ctx.service.served;
 	if (instances) *instances = t_ctx.service.started;
@@ -320,6 +366,30 @@ struct TextureCall {
 		if (!c.service.serve(payload, number, &failed)) return kNotTaken;	// (the service has switched itself off with a message; this call still gets its launch)
 		copy_out(c.service.pixels_host());
 		return failed ? block_failed() : kTrue;
+	}
+
+	// The caller's pixel buffer is one the library handed out (detexhipAllocPixelBuffer: pinned, device-visible): linear textures with up to
+	// Tune::kOwnedDirectBytes of pixels are written by the kernel straight into it -- blocks through the pinned exchange buffer, completion
+	// polled, nothing copied out.  Shader stores in the kernels' 1 KiB runs cross the link at the DMA engines' rate at these sizes (1 MiB
+	// 19 us of data, 4 MiB 87 vs 84; tools/ubench/host_midsize.hip), so the serial kernel -> download step of the staged path and the
+	// copy-out of the pinned exchange both disappear.  Larger textures take the staged path, whose download into pinned memory is the
+	// fastest copy there is.
+	Outcome via_owned_pixel_buffer() const {
+		if (tiled || out_bytes > Tune::kOwnedDirectBytes || in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
+		uint8_t *dev = owned_device_view(pixel_buffer, out_bytes);
+		if (!dev) return kNotTaken;
+		const int epi = prepared_epilogue(texture->format, pixel_format);
+		if (epi == -2) return kFalse;
+		DirectExchange x;
+		if (!direct_exchange(c, in_bytes, 0, &x)) return kFalse;
+		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
+		const uint32_t ticket = next_ticket(c);
+		bool empty = false;
+		if (!launch_rows(epi, x.d_base + x.in_off, dev, reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
+				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket }, &empty)) return kFalse;
+		if (!empty && !wait_for_ticket(c, x, ticket)) return kFalse;
+		return *reinterpret_cast<volatile uint32_t *>(x.h_base) != 0 ? block_failed() : kTrue;
 	}
 
 	// Blocks + pixels up to Tune::kHostDirectBytes: the kernel reads the blocks from, and writes pixels and status into, pinned host memory
@@ -456,12 +526,13 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
 		// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
 		tiled ? 0 : (width < 4u * wb ? width : 4u * wb), tiled ? 0 : (height < 4u * hb ? height : 4u * hb) };
-	// by size: the resident service (up to 1024 blocks, from the second call in a row on), the pinned exchange (up to 1.25 MiB in all),
-	// staging through device memory.  (Round 5 also built a fourth path -- the caller's pixel buffer registered with the runtime for the call,
+	// by size: the resident service (up to 1024 blocks, from the second call in a row on), a pixel buffer the library handed out (written
+	// directly, up to 8 MiB), the pinned exchange (up to 1.25 MiB in all), staging through device memory.  (Round 5 also built a fourth path -- the caller's pixel buffer registered with the runtime for the call,
 	// the kernel writing straight into it: 512^2 50.5 -> 41.1 us -- and took it out again: the third full test run with it ended in a GPU memory
 	// access fault at a host heap address during a LATER, unrelated copy of the same process.  Registering memory the library does not own,
 	// which its owner then frees, is not something this tier can make safe: profiles/r05/host_registered_output_fault.txt.)
 	Outcome r = call.via_resident_service();
+	if (r == kNotTaken) r = call.via_owned_pixel_buffer();
 	if (r == kNotTaken) r = call.via_pinned_exchange();
 	if (r == kNotTaken) r = call.via_staging();
 	return r == kTrue;

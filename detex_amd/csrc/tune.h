@@ -50,6 +50,8 @@ struct ProductTune {
 	// ... and larger textures whose BLOCKS fit in this many bytes hand them over through the same pinned buffer (read by the kernel across
 	// the link) instead of an upload out of pageable memory; 0 = always upload
 	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
+	// ... and a pixel buffer the library handed out (detexhipAllocPixelBuffer) is written by the kernel directly up to this many bytes of pixels
+	static constexpr unsigned long kOwnedDirectBytes = 8ul << 20;
 	// ETC2: most planar blocks per wave that are decoded cooperatively (0 = always in their own lanes)
 	static constexpr int kEtcPlanarShared = 8;
 };

@@ -36,6 +36,15 @@ extern "C" {
 DETEXHIP_API int detexhipGetDeviceCount(void);
 DETEXHIP_API int detexhipSetDevice(int device);
 DETEXHIP_API void detexhipReleaseThreadResources(void);
+/* Pixel buffers the kernels can write into directly.  The reference's callers malloc() the pixel_buffer they hand to
+ * detexDecompressTextureLinear (validate.c:199); the GPU cannot reach such memory, so the host tier decodes into a buffer of its own and
+ * copies (textures up to 1.25 MiB) or downloads (larger ones) into the caller's.  A pixel_buffer that lies inside memory returned by
+ * detexhipAllocPixelBuffer is pinned and device-visible: linear textures with up to 8 MiB of pixels are then written by the kernel
+ * straight into it -- same call, same result, no copy-out (512x512: 50 -> ~35 us, 1024x1024: 120 -> ~105 us per call); larger ones are
+ * downloaded into it at the link's rate.  One allocation may hold many images (any sub-range works).  Plain host memory otherwise: read
+ * and write it like malloc'ed memory, free it with detexhipFreePixelBuffer only.  NULL + error message on failure.  Thread-safe. */
+DETEXHIP_API void *detexhipAllocPixelBuffer(size_t bytes);
+DETEXHIP_API void detexhipFreePixelBuffer(void *pixel_buffer);
 DETEXHIP_API const char *detexhipVersion(void);
 /* The extension API's structs grow now and then (detexhipShard gained `peer_access` in 0.3 -> ABI 4): a client passes the
  * DETEXHIP_ABI_VERSION it was COMPILED with and gets 0 if this library lays the structs out the same way, non-zero (and an error

@@ -8,9 +8,10 @@
  *   detex_client --stream FORMAT BLOCKBYTES SEED W H     synthetic block stream U (splitmix64) of texture format word
  *                                                        FORMAT (detex.h:613-727), decoded and digested the same way
  *   detex_client --sha256-selftest       digest of "abc" and of 1,000,000 'a' (FIPS 180-4 vectors)
- *   detex_client --latency               microseconds per call (median of 2000) of detexDecompressBlockBC1 and of
+ *   detex_client --latency [owned]       microseconds per call (median of 2000) of detexDecompressBlockBC1 and of
  *                                        detexDecompressTextureLinear on 64x64 ... 4096x4096 BC1 and BC7 textures: what a C caller pays,
- *                                        without the ctypes overhead bench.py's host_tier_small carries
+ *                                        without the ctypes overhead bench.py's host_tier_small carries; `owned`: the pixel buffers come from
+ *                                        detexhipAllocPixelBuffer (pinned: the kernel writes straight into them)
  *   detex_client --blocks                n = 1, 1024, 1048576 independent blocks (BC1, BC7): the loop over the leaf function
  *                                        (detex.h:435-531) against ONE detexhipDecompressBlocks call (libdetexhip builds only:
  *                                        -DWITH_DETEXHIP), results compared block by block
@@ -101,7 +102,8 @@ static int decode_and_print(const char *label, const detexTexture *t) {
 static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 static int cmp_double(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
 
-static int latency(void) {
+/* owned != 0 (libdetexhip builds): the pixel buffers come from detexhipAllocPixelBuffer -- pinned, written by the kernel directly */
+static int latency(int owned) {
 	enum { N = 2000, WARM = 200 };
 	static double t[N];
 	uint8_t block[8] = { 0x12, 0x34, 0x56, 0x78, 0x9A, 0xBC, 0xDE, 0xF0 }, px[64], first[64];
@@ -124,7 +126,13 @@ static int latency(void) {
 			const int n = side <= 256 ? N : (side <= 1024 ? 300 : 40);	/* (the large ones take 0.1-25 ms per call on the CPU) */
 			const int warm = side <= 1024 ? WARM : 8;
 			const size_t nb = (size_t)(side / 4) * (side / 4), out_bytes = (size_t)side * side * 4;
-			uint8_t *blocks = (uint8_t *)malloc(nb * bs), *pixels = (uint8_t *)malloc(out_bytes), *expect = (uint8_t *)malloc(out_bytes);
+			uint8_t *blocks = (uint8_t *)malloc(nb * bs), *expect = (uint8_t *)malloc(out_bytes), *pixels;
+#ifdef WITH_DETEXHIP
+			pixels = owned ? (uint8_t *)detexhipAllocPixelBuffer(out_bytes) : (uint8_t *)malloc(out_bytes);
+#else
+			pixels = (uint8_t *)malloc(out_bytes);
+#endif
+			if (!pixels) { printf("latency ERROR %s\n", detexGetErrorMessage()); return 1; }
 			for (size_t k = 0; k < nb * bs; k++) blocks[k] = (uint8_t)(k * 2654435761u >> 13);
 			if (f) for (size_t k = 0; k < nb; k++) blocks[k * bs] |= 1;		/* BC7: every block valid (mode 0), so the call returns true */
 			detexTexture tex;
@@ -139,8 +147,13 @@ static int latency(void) {
 				else if (((i + warm) & 255) == 1 && memcmp(expect, pixels, 64) == 0) wrong++;
 			}
 			qsort(t, n, sizeof t[0], cmp_double);
-			printf("latency %s%dx%d_us=%.2f p90=%.2f\n", f ? "bc7_" : "", side, side, t[n / 2], t[n * 9 / 10]);
-			free(blocks); free(pixels); free(expect);
+			printf("latency %s%s%dx%d_us=%.2f p90=%.2f\n", owned ? "owned_" : "", f ? "bc7_" : "", side, side, t[n / 2], t[n * 9 / 10]);
+			free(blocks); free(expect);
+#ifdef WITH_DETEXHIP
+			if (owned) detexhipFreePixelBuffer(pixels); else free(pixels);
+#else
+			free(pixels);
+#endif
 		}
 	}
 	printf("latency wrong_results=%d\n", wrong);
@@ -208,7 +221,7 @@ static int blocks_mode(void) {
 }
 
 int main(int argc, char **argv) {
-	if (argc >= 2 && !strcmp(argv[1], "--latency")) return latency();
+	if (argc >= 2 && !strcmp(argv[1], "--latency")) return latency(argc >= 3 && !strcmp(argv[2], "owned"));
 	if (argc >= 2 && !strcmp(argv[1], "--blocks")) return blocks_mode();
 	if (argc >= 2 && !strcmp(argv[1], "--sha256-selftest")) {
 		char hex[65];

@@ -65,6 +65,9 @@ int main() {
 	REFUSED(detexhipDecompressBlocks(BC1, in, 4, DETEX_MODE_MASK_ALL, 0, nullptr, nullptr));
 	REFUSED(detexhipDecompressBlocks(BC1, in, (size_t)1 << 40, DETEX_MODE_MASK_ALL, 0, out, nullptr));
 	if (!detexhipDecompressBlocks(BC1, nullptr, 0, DETEX_MODE_MASK_ALL, 0, nullptr, nullptr)) { printf("zero blocks must succeed\n"); g_failures++; }
+	{ int not_ours = 0; detexSetErrorMessage("(none)"); detexhipFreePixelBuffer(&not_ours);		// a foreign pointer: refused, nothing freed
+	  if (!detexGetErrorMessage() || !strstr(detexGetErrorMessage(), "was not returned")) { printf("detexhipFreePixelBuffer accepted a foreign pointer\n"); g_failures++; } }
+	detexhipFreePixelBuffer(nullptr);
 	REFUSED(detexhipCheckAbi(DETEXHIP_ABI_VERSION + 1) == 0);
 	if (detexhipCheckAbi(DETEXHIP_ABI_VERSION) != 0) { printf("the header's own ABI version was refused\n"); g_failures++; }
 	// mip levels

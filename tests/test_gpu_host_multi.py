@@ -423,3 +423,80 @@ def test_block_grid_taller_than_the_image(W, H, wb, hb, hiplib, oracle, ref):
     for rep in range(2):
         ok, got = hiplib.linear(fmt, data, W, H, wb=wb, hb=hb)
         assert not ok and np.array_equal(got, want), (W, H, rep)
+
+
+# ---- pixel buffers handed out by the library (detexhipAllocPixelBuffer): the kernel writes straight into them --------------------------------
+def _owned(lib, nbytes):
+    lib.detexhipAllocPixelBuffer.restype = ctypes.c_void_p
+    lib.detexhipAllocPixelBuffer.argtypes = [ctypes.c_size_t]
+    lib.detexhipFreePixelBuffer.argtypes = [ctypes.c_void_p]
+    lib.detexhipFreePixelBuffer.restype = None
+    p = lib.detexhipAllocPixelBuffer(nbytes)
+    assert p, lib.detexGetErrorMessage()
+    return p, np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p))
+
+
+@pytest.mark.parametrize("name,W,H,wb,hb", [("BC1", 512, 512, None, None), ("BPTC", 1024, 1024, None, None), ("BPTC", 701, 333, None, None), ("BC3", 1401, 1399, None, None),
+                                            ("RGTC1", 2048, 1024, None, None), ("BPTC_FLOAT", 512, 384, None, None), ("ETC2", 900, 400, 200, 90), ("BC1", 2048, 2048, None, None),
+                                            ("BC1", 64, 64, None, None), ("ETC2_EAC", 300, 200, None, None)])
+def test_library_owned_pixel_buffers(name, W, H, wb, hb, hiplib, oracle):
+    """detexDecompressTextureLinear into a sub-range of a buffer from detexhipAllocPixelBuffer: the direct-write path (up to 8 MiB of pixels:
+    whole and clipped sizes, a grid smaller than the image, invalid blocks, 64-bit and narrow pixels), the resident service (64^2), the staged
+    path downloading into pinned memory (2048^2) -- pixels == the oracle, bytes around the image untouched, twice each"""
+    fmt = F.BY_NAME[name]
+    gwb, ghb = (W + 3) // 4 if wb is None else wb, (H + 3) // 4 if hb is None else hb
+    data = ol.stream_u(fmt, gwb * ghb, seed=0x0B0F + fmt.index + W)
+    px = fmt.pixel_bytes
+    n = W * H * px
+    ptr, whole = _owned(hiplib.lib, n + 4096 + 160)
+    try:
+        for rep, off in enumerate((64, 4096 + 16)):                              # the image anywhere inside the allocation
+            whole[:] = 0xA5
+            ok, got = hiplib.linear(fmt, data, W, H, out=whole[off:off + n], wb=gwb, hb=ghb)
+            cw, ch = min(W, 4 * gwb), min(H, 4 * ghb)
+            want_ok, want = oracle.linear(fmt, data, cw, ch)
+            img = got.reshape(H, W * px)
+            assert np.array_equal(img[:ch, :cw * px].reshape(-1), want.reshape(-1)), (name, W, H, rep)
+            assert (img[:ch, cw * px:] == 0xA5).all() and (img[ch:] == 0xA5).all(), "pixels outside the block grid were written"
+            assert (whole[:off] == 0xA5).all() and (whole[off + n:] == 0xA5).all(), "wrote outside the image"
+            assert ok == want_ok
+            if not ok:
+                assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+    finally:
+        hiplib.lib.detexhipFreePixelBuffer(ptr)
+
+
+def test_library_owned_pixel_buffers_lifecycle(hiplib, oracle):
+    """freeing twice, freeing a foreign pointer (refused with a message, nothing freed), NULL (ignored); a buffer that has been freed is an
+    ordinary pointer again; two threads decoding into their own owned buffers"""
+    import threading
+    lib = hiplib.lib
+    fmt = F.BY_NAME["BC1"]
+    p, view = _owned(lib, 1 << 20)
+    lib.detexhipFreePixelBuffer(p)
+    lib.detexSetErrorMessage(b"(none)")
+    lib.detexhipFreePixelBuffer(p)                                                 # second free: refused
+    assert "was not returned by detexhipAllocPixelBuffer" in hiplib.error()
+    lib.detexhipFreePixelBuffer(None)
+    data = ol.stream_u(fmt, 128 * 128, seed=3)
+    _, want = oracle.linear(fmt, data, 512, 512)
+    ok, got = hiplib.linear(fmt, data, 512, 512)                                    # an ordinary numpy buffer afterwards: the other paths
+    assert ok and np.array_equal(got, want)
+    errors = []
+
+    def worker(k):
+        try:
+            api = ol.DetexAPI(hiplib.path)
+            ptr, buf = _owned(api.lib, 512 * 512 * 4)
+            for _ in range(50):
+                buf[:] = 0
+                ok, got = api.linear(fmt, data, 512, 512, out=buf)
+                if not ok or not np.array_equal(got, want):
+                    errors.append((k, "mismatch")); break
+            api.lib.detexhipFreePixelBuffer(ptr)
+        except Exception as e:   # noqa
+            errors.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
