@@ -866,6 +866,14 @@ def main():
                     cc["note"] = ("median of 2000 back-to-back calls, compiled C, same library: from the second call on the requests are answered by the resident "
                                   "kernel (detexhipSetResidentIdleMicroseconds; 256x256 is beyond it: one launch per call, completion polled)")
                     small["gpu_compiled_c_client"] = cc
+                def client_latency_owned(path):
+                    r = subprocess.run([path, "--latency", "owned"], capture_output=True, text=True, timeout=120)
+                    return {l.split()[1].split("=")[0]: float(l.split()[1].split("=")[1]) for l in r.stdout.splitlines() if l.startswith("latency ") and "=" in l}
+                cc = client_latency_owned(client)
+                if cc:
+                    cc["note"] = ("the same calls with pixel buffers from detexhipAllocPixelBuffer (pinned, device-visible): linear textures with up to 8 MiB of "
+                                  "pixels are written by the kernel straight into the caller's buffer, nothing is copied out")
+                    small["gpu_compiled_c_client_owned_pixel_buffers"] = cc
                 cc = client_latency(client, dict(os.environ, DETEXHIP_RESIDENT_US="0"))
                 if cc:
                     cc["note"] = "the same with DETEXHIP_RESIDENT_US=0: one launch per call, completion by polling a word the kernel releases in pinned memory"

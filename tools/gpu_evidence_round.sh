@@ -15,6 +15,7 @@ echo "== bench (driver line, N=1)"; ( time timeout 600 python bench.py --steps 2
 echo "== compiled C client: fixtures, latency, batched blocks"
 tests/c_client/detex_client tests/golden/test-texture-BC1.ktx tests/golden/test-texture-BPTC_FLOAT.ktx | tee $OUT/c_client.txt
 tests/c_client/detex_client --latency | tee -a $OUT/c_client.txt | head -3
+echo "-- pixel buffers from detexhipAllocPixelBuffer (pinned: the kernel writes straight into them)" >> $OUT/c_client.txt; tests/c_client/detex_client --latency owned >> $OUT/c_client.txt
 echo "-- the same with DETEXHIP_RESIDENT_US=0 (a launch per call)" >> $OUT/c_client.txt; DETEXHIP_RESIDENT_US=0 tests/c_client/detex_client --latency >> $OUT/c_client.txt
 echo "-- the same program linked against the compiled reference (one host thread)" >> $OUT/c_client.txt; [ -x tests/c_client/detex_client_reflib ] && tests/c_client/detex_client_reflib --latency >> $OUT/c_client.txt
 echo "-- n independent blocks: the loop over the leaf function against ONE detexhipDecompressBlocks call" >> $OUT/c_client.txt; tests/c_client/detex_client --blocks | tee -a $OUT/c_client.txt
