@@ -40,7 +40,8 @@ DETEXHIP_API void detexhipReleaseThreadResources(void);
  * detexDecompressTextureLinear (validate.c:199); the GPU cannot reach such memory, so the host tier decodes into a buffer of its own and
  * copies (textures up to 1.25 MiB) or downloads (larger ones) into the caller's.  A pixel_buffer that lies inside memory returned by
  * detexhipAllocPixelBuffer is pinned and device-visible: linear textures with up to 8 MiB of pixels are then written by the kernel
- * straight into it -- same call, same result, no copy-out (512x512: 50 -> ~35 us, 1024x1024: 120 -> ~105 us per call); larger ones are
+ * straight into it -- same call, same result, no copy-out (256x256: 20 -> 15 us, 512x512: 50 -> 31 us, 1024x1024: 118 -> 108-111 us per
+ * call from compiled C; the first two are the PCIe floor); larger ones are
  * downloaded into it at the link's rate.  One allocation may hold many images (any sub-range works).  Plain host memory otherwise: read
  * and write it like malloc'ed memory, free it with detexhipFreePixelBuffer only.  NULL + error message on failure.  Thread-safe. */
 DETEXHIP_API void *detexhipAllocPixelBuffer(size_t bytes);
