@@ -380,13 +380,15 @@ struct TextureCall {
 		if (!dev) return kNotTaken;
 		const int epi = prepared_epilogue(texture->format, pixel_format);
 		if (epi == -2) return kFalse;
+		// (the blocks may live in such a buffer too -- it is ordinary pinned memory: then the kernel reads them where they are)
+		const uint8_t *dev_blocks = reinterpret_cast<uintptr_t>(texture->data) % bs == 0 ? owned_device_view(texture->data, in_bytes) : nullptr;	// (a block is one 8 / 16-byte load)
 		DirectExchange x;
-		if (!direct_exchange(c, in_bytes, 0, &x)) return kFalse;
-		memcpy(x.h_base + x.in_off, texture->data, in_bytes);
+		if (!direct_exchange(c, dev_blocks ? 0 : in_bytes, 0, &x)) return kFalse;
+		if (!dev_blocks) { memcpy(x.h_base + x.in_off, texture->data, in_bytes); dev_blocks = x.d_base + x.in_off; }
 		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
 		const uint32_t ticket = next_ticket(c);
 		bool empty = false;
-		if (!launch_rows(epi, x.d_base + x.in_off, dev, reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
+		if (!launch_rows(epi, dev_blocks, dev, reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
 				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket }, &empty)) return kFalse;
 		if (!empty && !wait_for_ticket(c, x, ticket)) return kFalse;
 		return *reinterpret_cast<volatile uint32_t *>(x.h_base) != 0 ? block_failed() : kTrue;

@@ -42,7 +42,8 @@ DETEXHIP_API void detexhipReleaseThreadResources(void);
  * detexhipAllocPixelBuffer is pinned and device-visible: linear textures with up to 8 MiB of pixels are then written by the kernel
  * straight into it -- same call, same result, no copy-out (256x256: 20 -> 15 us, 512x512: 50 -> 31 us, 1024x1024: 118 -> 108-111 us per
  * call from compiled C; the first two are the PCIe floor); larger ones are
- * downloaded into it at the link's rate.  One allocation may hold many images (any sub-range works).  Plain host memory otherwise: read
+ * downloaded into it at the link's rate.  One allocation may hold many images (any sub-range works), and the compressed blocks as well
+ * (texture->data inside such memory is read by the kernel where it is: one copy less).  Plain host memory otherwise: read
  * and write it like malloc'ed memory, free it with detexhipFreePixelBuffer only.  NULL + error message on failure.  Thread-safe. */
 DETEXHIP_API void *detexhipAllocPixelBuffer(size_t bytes);
 DETEXHIP_API void detexhipFreePixelBuffer(void *pixel_buffer);

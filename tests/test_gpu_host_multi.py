@@ -462,6 +462,18 @@ def test_library_owned_pixel_buffers(name, W, H, wb, hb, hiplib, oracle):
             assert ok == want_ok
             if not ok:
                 assert hiplib.error() == "detexDecompressBlock: Decompress function for format 0x%08X returned error" % fmt.texture_format
+        # the BLOCKS in owned memory as well (16-byte aligned inside it): read by the kernel where they are
+        pb, blocks_view = _owned(hiplib.lib, data.size + 64)
+        try:
+            blocks_view[16:16 + data.size] = data
+            whole[:] = 0xA5
+            ok, got = hiplib.linear(fmt, blocks_view[16:16 + data.size], W, H, out=whole[64:64 + n], wb=gwb, hb=ghb)
+            assert ok == want_ok and np.array_equal(got.reshape(H, W * px)[:ch, :cw * px].reshape(-1), want.reshape(-1))
+            blocks_view[3:3 + data.size] = data                                    # ... and misaligned inside it: copied like any other host pointer
+            ok, got = hiplib.linear(fmt, blocks_view[3:3 + data.size], W, H, out=whole[64:64 + n], wb=gwb, hb=ghb)
+            assert ok == want_ok and np.array_equal(got.reshape(H, W * px)[:ch, :cw * px].reshape(-1), want.reshape(-1))
+        finally:
+            hiplib.lib.detexhipFreePixelBuffer(pb)
     finally:
         hiplib.lib.detexhipFreePixelBuffer(ptr)
 
