@@ -7,12 +7,16 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := detex_amd/csrc
 LIB   := detex_amd/lib/libdetexhip.so
-LIB_AB := build/explib/libdetexhip_ab.so
+# (under tests/: build/ does not travel to the GPU box -- .gpurunignore -- and tests/test_ab_variants.py loads this build itself)
+LIB_AB := tests/ab_build/libdetexhip_ab.so
 HDRS  := $(wildcard $(CSRC)/*.h) $(CSRC)/bptc_tables.inc include/detex.h include/detexhip.h
 
 all: lib oracle ubench c-client
 lib: $(LIB)
-ubench: tools/ubench/valu_rates tools/ubench/host_latency tools/ubench/host_midsize hbmref
+ubench: tools/ubench/valu_rates tools/ubench/host_latency tools/ubench/host_midsize tools/ubench/big_footprint hbmref
+# (links the product library: the large-footprint sweep goes through the device entry itself)
+tools/ubench/big_footprint: tools/ubench/big_footprint.hip include/detexhip.h $(LIB)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
 tools/ubench/host_midsize: tools/ubench/host_midsize.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -pthread -o $@ $<
 tools/ubench/host_latency: tools/ubench/host_latency.hip
@@ -81,6 +85,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/big_footprint tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
 .PHONY: all lib lib-ab api-san c-client oracle ubench hbmref clean

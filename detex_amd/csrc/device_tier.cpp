@@ -93,6 +93,14 @@ uint32_t current_spec_flags() {
 	return ((s.quirks & DETEXHIP_QUIRK_BC7_MODE6_PBIT) ? 0u : kFlagSpecBc7Mode6PBit) | ((s.quirks & DETEXHIP_QUIRK_BC6H_MODE12_BIT63) ? 0u : kFlagSpecBc6hMode12Bit63);
 }
 
+// Read-ahead of the blocks of textures beyond the Infinity Cache (linear_device_with): on unless switched off for the calling thread
+// (detexhipSetReadAhead, or DETEXHIP_READ_AHEAD=0 in the environment when the thread first decodes)
+bool current_read_ahead() {
+	ThreadSettings &s = t_settings;
+	if (s.read_ahead < 0) { const char *env = getenv("DETEXHIP_READ_AHEAD"); s.read_ahead = env ? (atoi(env) != 0) : 1; }
+	return s.read_ahead != 0;
+}
+
 int linear_device_with(uint32_t texture_format, const void *d_blocks, int width, int height, int width_in_blocks, int height_in_blocks,
 		void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant) {
 	const FormatEntry *f = lookup_format(texture_format);
@@ -122,6 +130,27 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 	if (f->resident_beyond_cache >= 0 &&
 			(size_t)width_in_blocks * (size_t)height_in_blocks * (detexGetCompressedBlockSize(texture_format) + 16u * px) > Tune::kInfinityCacheBytes)
 		g.resident = f->resident_beyond_cache;
+	// Blocks that cannot be resident in the Infinity Cache (more of them than it holds) come out of HBM in the middle of the write stream,
+	// and HBM serves a read scattered among writes three times slower than a read from that cache (TCC_EA0_RDREQ_LEVEL / RDREQ: 2980 vs
+	// 1000 cycles; the whole 32768^2 BC1 image 815 us where its four quarters, decoded alone, take 4 x 163: profiles/r06/footprint/).
+	// Such textures go in bands of block rows -- a band is one contiguous range of blocks and of image rows, texture.c:115-141 -- each
+	// band's blocks read into the cache by a read-only pass first: a read phase and a write phase per band, on the caller's stream.
+	const size_t bs = detexGetCompressedBlockSize(texture_format), row_bytes = (size_t)width_in_blocks * bs;
+	const bool whole_grid = (size_t)width_in_blocks * 4u == (size_t)width && (size_t)height_in_blocks * 4u == (size_t)height;
+	if (current_read_ahead() && whole_grid && row_bytes * (size_t)height_in_blocks > Tune::kInfinityCacheBytes && row_bytes > 0 && row_bytes <= Tune::kReadAheadBandBytes) {
+		const uint32_t band_rows = (uint32_t)(Tune::kReadAheadBandBytes / row_bytes);
+		for (uint32_t r0 = 0; r0 < (uint32_t)height_in_blocks; r0 += band_rows) {
+			const uint32_t rows = r0 + band_rows < (uint32_t)height_in_blocks ? band_rows : (uint32_t)height_in_blocks - r0;
+			Geometry band = g;
+			band.blocks = static_cast<const uint8_t *>(d_blocks) + (size_t)r0 * row_bytes;
+			band.pixels = static_cast<uint8_t *>(d_pixels) + (size_t)r0 * 4u * pitch_bytes;
+			band.hb = rows; band.height = rows * 4u;
+			hipError_t e = launch_read_ahead(band.blocks, (size_t)rows * row_bytes, band.stream);
+			if (e == hipSuccess) e = f->linear(band);
+			if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+		}
+		return 0;
+	}
 	hipError_t e = f->linear(g);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
@@ -149,6 +178,8 @@ extern "C" int detexhipCheckAbi(int compiled_against) {
 
 extern "C" void detexhipSetQuirks(uint32_t quirks) { thread_settings().quirks = (int)(quirks & DETEXHIP_QUIRKS_REFERENCE); }
 extern "C" uint32_t detexhipGetQuirks(void) { (void)current_spec_flags(); return (uint32_t)thread_settings().quirks; }
+
+extern "C" int detexhipSetReadAhead(int on) { const int before = current_read_ahead() ? 1 : 0; thread_settings().read_ahead = on ? 1 : 0; return before; }
 
 extern "C" void detexhipSetKernelVariant(int variant) { thread_settings().variant = (variant >= 0 && variant <= max_variant()) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }

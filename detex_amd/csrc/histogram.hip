@@ -145,6 +145,34 @@ static int mode_histogram_device(uint32_t texture_format, const void *d_blocks, 
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;
 }
+// ---- read-ahead of a block range into the memory-side cache (device_tier.cpp: linear_device_with) -----------------------------------------------
+// A read-only pass over [p, p + bytes): every 16-byte vector loaded once with the default cache policy -- which allocates in the 256 MiB
+// Infinity Cache -- and dropped.  Workgroup = 1024 lanes x 4 vectors = 64 KiB, every wave instruction one contiguous 1 KiB run, all four
+// loads of a lane in flight together (tools/ubench/big_footprint.hip: 512 MiB in 85 us = 6.3 TB/s with four loads per lane, 99 us with one).
+namespace detexhip {
+__global__ __launch_bounds__(1024) void read_ahead(const u32x4 *__restrict__ p, uint64_t n_vectors) {
+	const uint64_t base = (uint64_t)blockIdx.x * 4096u + threadIdx.x;
+	const u32x4 *q[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) { const uint64_t i = base + 1024u * (uint32_t)k; q[k] = p + (i < n_vectors ? i : n_vectors - 1u); }
+	// (the values are not wanted, only the lines' arrival in the cache: the loads are `asm volatile` so that the compiler keeps them --
+	// written as plain loads into an unused sink the whole kernel was compiled to s_endpgm -- and waited for before the wave ends)
+	u32x4 a, b, c, d;
+	asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+		"global_load_dwordx4 %1, %5, off\n\t"
+		"global_load_dwordx4 %2, %6, off\n\t"
+		"global_load_dwordx4 %3, %7, off\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]) : "memory");
+}
+hipError_t launch_read_ahead(const void *p, size_t bytes, hipStream_t stream) {
+	const uint64_t n_vectors = bytes / 16u;
+	if (n_vectors == 0) return hipSuccess;
+	hipLaunchKernelGGL(read_ahead, dim3((unsigned)((n_vectors + 4095u) / 4096u)), dim3(1024), 0, stream, static_cast<const u32x4 *>(p), n_vectors);
+	return hipGetLastError();
+}
+}  // namespace detexhip
+
 extern "C" int detexhipModeHistogramDevice(uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t *d_hist, void *stream) {
 	return mode_histogram_device(texture_format, d_blocks, n_blocks, d_hist, stream, true);
 }

@@ -85,7 +85,7 @@ uint8_t half_to_u8_entry(uint32_t half_bits);				// formats_bptc_float.hip (host
 bool stream_on_current_device(hipStream_t stream, const char *who);
 
 // ---- per-thread settings (device_tier.cpp): detexhipSetDevice / SetQuirks / SetKernelVariant ------------------------------------
-struct ThreadSettings { int device = -1, variant = -1, quirks = -1; };	// -1 = not read yet (environment / default)
+struct ThreadSettings { int device = -1, variant = -1, quirks = -1, read_ahead = -1; };	// -1 = not read yet (environment / default)
 ThreadSettings &thread_settings();
 int current_variant();
 uint32_t current_spec_flags();						// the decoders' kFlagSpec... bits for the calling thread's quirk mask
@@ -99,6 +99,9 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 
 // ---- 8f-4 (histogram.hip) ----------------------------------------------------------------------------------------------------------
 hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first);
+
+// ---- read-ahead of compressed blocks into the Infinity Cache (histogram.hip; used by device_tier.cpp for inputs beyond that cache) ------------
+hipError_t launch_read_ahead(const void *p, size_t bytes, hipStream_t stream);
 
 // ---- resident service of the host tier's smallest calls (host_resident.cpp; protocol: path_types.h ResidentMail) ---------------------
 // One per host-tier thread context.  All of it runs with the context's device current.
@@ -130,7 +133,7 @@ private:
 	bool prepare(int device);
 	bool launch(uint32_t start_seq);
 	void post(const uint32_t payload[12], uint32_t number);
-	bool stop();
+	bool stop(bool quiet = false);	// quiet: a failure sets no error message (the caller's call goes on without the service)
 };
 int resident_idle_microseconds();	// detexhipSetResidentIdleMicroseconds, else DETEXHIP_RESIDENT_US, else 100; 0 = no resident kernels
 

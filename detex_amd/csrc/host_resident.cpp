@@ -45,7 +45,9 @@ bool ResidentService::wanted(const FormatEntry *fmt, int epilogue) {
 	// A call that does not continue the row ends the running instance NOW (a stop request and its answer: one round trip across the
 	// link) instead of leaving it to spin out its idle time: what such a call does next -- hipMalloc / hipFree of staging buffers, a
 	// table upload -- synchronises with the device and would wait behind that kernel, as would other streams sharing its hardware queue.
-	if (!repeat && launched) (void)stop();
+	// (quiet: a failure here marks the service broken, but THIS call goes on to its own launch and may well succeed -- it must not leave
+	// a 'resident kernel failed' text behind a call that returns true)
+	if (!repeat && launched) (void)stop(true);
 	if (!repeat || broken || resident_idle_microseconds() <= 0) return false;
 	int device = 0;
 	if (hipGetDevice(&device) != hipSuccess) return false;
@@ -121,7 +123,7 @@ void ResidentService::post(const uint32_t payload[12], uint32_t number) {
 }
 
 // ends the running instance (a request it must see before the next one may be posted: the next one may be for another format's kernel)
-bool ResidentService::stop() {
+bool ResidentService::stop(bool quiet) {
 	if (!launched) return true;
 	ResidentMail *mail = reinterpret_cast<ResidentMail *>(h_buf);
 	uint32_t payload[12] = {};
@@ -134,7 +136,12 @@ bool ResidentService::stop() {
 		if ((polls & 0x3FFFu) == 0u) {
 			const hipError_t e = hipStreamQuery(stream);
 			if (e == hipErrorNotReady) continue;
-			if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: the resident kernel failed: %s", hipGetErrorString(e)); launched = false; broken = true; return false; }
+			if (e != hipSuccess) {
+				if (!quiet) detexSetErrorMessage("libdetexhip: the resident kernel failed: %s", hipGetErrorString(e));
+				(void)hipGetLastError();
+				launched = false; broken = true;
+				return false;
+			}
 			break;		// the stream is idle: no instance left, whatever the word says
 		}
 	}

@@ -3,6 +3,8 @@
 // every entry point, including the one-block leaf functions, runs the gfx950 kernels; without a usable HIP device the calls
 // fail with an error message.  Host code only.
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -18,18 +20,52 @@ namespace {
 // Pinned, device-visible host memory handed to the caller to be used as the pixel_buffer of the texture drivers: a kernel can write straight
 // into it (no staging buffer on the host side of the link, no copy-out -- what the removed registered-output path did with memory the
 // library did NOT own).  Process-wide registry, a handful of entries; looked up per call under a mutex (tens of nanoseconds).
-struct OwnedBuffer { uint8_t *host, *dev; size_t bytes; };
+struct OwnedBuffer { uint8_t *host, *dev; size_t bytes; unsigned in_use; };
 std::mutex g_owned_mutex;
+std::condition_variable g_owned_idle;		// signalled when an in_use count drops to zero (detexhipFreePixelBuffer waits on it)
 std::vector<OwnedBuffer> g_owned;
-// device view of [p, p + n) if that range lies inside one owned buffer
-uint8_t *owned_device_view(const void *p, size_t n) {
-	const uint8_t *q = static_cast<const uint8_t *>(p);
-	std::lock_guard<std::mutex> lock(g_owned_mutex);
-	for (const OwnedBuffer &b : g_owned)
-		if (q >= b.host && n <= b.bytes && (size_t)(q - b.host) <= b.bytes - n) return b.dev + (q - b.host);
-	return nullptr;
-}
+// A decode that reads or writes an owned buffer directly HOLDS it from the lookup until its kernel has completed (or is known never to
+// complete): detexhipFreePixelBuffer from another thread waits for the count to drop instead of freeing memory a kernel is still writing.
+struct OwnedHold {
+	uint8_t *base = nullptr;		// host base of the held buffer (its key in the registry)
+	OwnedHold() = default;
+	OwnedHold(const OwnedHold &) = delete;
+	OwnedHold &operator=(const OwnedHold &) = delete;
+	// device view of [p, p + n) if that range lies inside one owned buffer (which is then held), else nullptr
+	uint8_t *acquire(const void *p, size_t n) {
+		const uint8_t *q = static_cast<const uint8_t *>(p);
+		std::lock_guard<std::mutex> lock(g_owned_mutex);
+		for (OwnedBuffer &b : g_owned)
+			if (q >= b.host && n <= b.bytes && (size_t)(q - b.host) <= b.bytes - n) { b.in_use++; base = b.host; return b.dev + (q - b.host); }
+		return nullptr;
+	}
+	void release() {
+		if (!base) return;
+		std::lock_guard<std::mutex> lock(g_owned_mutex);
+		for (OwnedBuffer &b : g_owned)
+			if (b.host == base) { if (--b.in_use == 0) g_owned_idle.notify_all(); break; }
+		base = nullptr;
+	}
+	~OwnedHold() { release(); }
+};
 
+// The words of ThreadContext::d_status (device memory, zero between calls), shared with histogram.hip's 16-bin result
+constexpr int kStatusWords = 32;
+constexpr int kStatusHistogramBins = 16;	// [0] the status word of the staged batch / mip-chain paths; [0..15] the bins of detexhipModeHistogram
+constexpr int kStatusBandCounters = 16;		// [16..19] workgroup counters of the small calls' completions (Completion::counter), one per band
+constexpr int kStagedStatusWord = 24;		// [24] the status word of the staged texture path
+constexpr int kDirectBands = 4;
+static_assert(kStatusBandCounters >= kStatusHistogramBins && kStatusBandCounters + kDirectBands <= kStagedStatusWord && kStagedStatusWord < kStatusWords,
+	"the histogram bins, the band counters and the staged status word must not overlap");
+
+// Test hook (detexhipTestFailAfterLaunch): the next N host-tier calls of this thread return false right after their kernels were launched
+thread_local int t_fail_after_launch = 0;
+bool injected_failure() {
+	if (t_fail_after_launch <= 0) return false;
+	t_fail_after_launch--;
+	detexSetErrorMessage("libdetexhip: injected failure after launch (detexhipTestFailAfterLaunch)");
+	return true;
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-thread device context of the host-pointer tier: a stream and grow-only device staging buffers that
@@ -41,8 +77,12 @@ struct ThreadContext {
 	hipStream_t stream = nullptr;
 	void *d_in = nullptr, *d_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
-	uint32_t *d_status = nullptr;	// 32 words: [0] status word, [0..15] histogram bins, [16..19] workgroup counters of the small calls' completions (Completion::counter),
-					// [24] the status word of the staged texture path, which is ZERO between calls (kStagedStatusWord)
+	uint32_t *d_status = nullptr;	// kStatusWords words, all ZERO between calls (layout: kStatus... above)
+	// A call sets `dirty` before its first launch and clears it when everything it launched is known to have finished with the device
+	// words back at zero.  A call that fails in between (a launch, a copy or a wait refused by the runtime) leaves it set, and the NEXT
+	// call on this thread first drains the stream and zeroes the words again (heal_if_dirty) -- instead of inheriting a raised status
+	// word, a half-counted completion counter or kernels still writing into the pinned buffer it is about to fill.
+	bool dirty = false;
 	uint32_t ticket = 0;		// last completion ticket handed out (never 0: the completion word starts as 0)
 	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
 	uint8_t *h_pin = nullptr, *d_pin = nullptr;
@@ -61,7 +101,7 @@ struct ThreadContext {
 		d_in = d_out = nullptr; d_status = nullptr; in_cap = out_cap = 0;
 		h_pin = d_pin = nullptr; pin_cap = 0;
 		stream = nullptr;
-		ready = false;
+		ready = false; dirty = false;
 		if (prev >= 0) (void)hipSetDevice(prev);
 	}
 	~ThreadContext() { release(); }
@@ -103,8 +143,11 @@ bool context_ready() {
 	if (!scope.ok) return false;
 	auto create = [&]() -> bool {
 		HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate");
-		HIP_TRY(hipMalloc(&c.d_status, 128), "hipMalloc(status)");
-		HIP_TRY(hipMemset(c.d_status, 0, 128), "hipMemset(status)");
+		HIP_TRY(hipMalloc(&c.d_status, kStatusWords * sizeof(uint32_t)), "hipMalloc(status)");
+		// zeroed by a COPY on the context's own stream, not by hipMemset: in a fresh process the first fill makes the runtime load its own
+		// fill kernels (9.7 ms in the one-shot client's API trace, profiles/r06/oneshot/) and a fill on the null stream a second hardware queue
+		static const uint32_t zeros[kStatusWords] = {};
+		HIP_TRY(hipMemcpyAsync(c.d_status, zeros, sizeof zeros, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(status)");
 		return true;
 	};
 	if (!create()) {			// nothing half-made is kept: the next call starts over
@@ -116,6 +159,25 @@ bool context_ready() {
 	c.ready = true;
 	return true;
 }
+
+// The previous call on this thread failed after it had launched something: wait for whatever is still running, put the device words
+// and the pinned header back to zero.  A stream that reports an error is beyond repair: the context is rebuilt from scratch.
+bool heal_if_dirty() {
+	ThreadContext &c = t_ctx;
+	if (!c.dirty) return true;
+	DeviceScope scope(c.device);
+	if (!scope.ok) return false;
+	if (hipStreamSynchronize(c.stream) != hipSuccess || hipMemset(c.d_status, 0, kStatusWords * sizeof(uint32_t)) != hipSuccess) {
+		(void)hipGetLastError();
+		c.release();
+		return context_ready();
+	}
+	if (c.h_pin) memset(c.h_pin, 0, 256);
+	c.dirty = false;
+	return true;
+}
+// context_ready() + heal_if_dirty(): what every entry point of this file calls first
+bool context_usable() { return context_ready() && heal_if_dirty(); }
 
 bool reserve(void **buf, size_t *cap, size_t need) {
 	if (need <= *cap) return true;
@@ -159,9 +221,7 @@ constexpr size_t kDoneOffset = 8;		// the completion word inside the exchange bu
 uint32_t next_ticket(ThreadContext &c) { if (++c.ticket == 0u) c.ticket = 1u; return c.ticket; }
 // Spins on the completion word the kernel just launched on c.stream releases.  Every 2^14 polls (a few hundred microseconds) the
 // stream is asked whether it failed or finished without the word (a kernel that faulted never publishes): no unbounded wait.
-constexpr int kStagedStatusWord = 24;		// ThreadContext::d_status
 constexpr size_t kBandDoneOffset = 64;		// ... and of band k of a banded call: kBandDoneOffset + 16 * k (k < kDirectBands)
-constexpr int kDirectBands = 4;
 bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket, size_t word_offset = kDoneOffset) {
 	const uint32_t *word = reinterpret_cast<const uint32_t *>(x.h_base + word_offset);
 	for (uint32_t polls = 1;; polls++) {
@@ -181,7 +241,7 @@ bool wait_for_ticket(ThreadContext &c, const DirectExchange &x, uint32_t ticket,
 // Returns 1 = decoded, 0 = the decoder returned false, -1 = HIP/runtime failure (message set).
 int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags,
 		uint8_t *pixel_buffer, uint32_t pixel_format) {
-	if (!context_ready()) return -1;
+	if (!context_usable()) return -1;
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return -1;
@@ -210,10 +270,13 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 		const uint32_t ticket = next_ticket(c);
 		SingleArgs a{ bitstring, mode_mask, decode_flags, reinterpret_cast<uint32_t *>(x.d_base + x.out_off), x.d_base + 4, c.stream, epi,
 			reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), ticket };
+		c.dirty = true;
 		HIP_TRY(f->single(a), "kernel launch");
+		if (injected_failure()) return false;
 		return wait_for_ticket(c, x, ticket);
 	};
 	if (!run()) return -1;
+	c.dirty = false;
 	if (!x.h_base[4]) return 0;
 	memcpy(pixel_buffer, x.h_base + x.out_off, out_bytes);
 	return 1;
@@ -237,20 +300,28 @@ extern "C" void *detexhipAllocPixelBuffer(size_t bytes) {
 		return nullptr;
 	}
 	std::lock_guard<std::mutex> lock(g_owned_mutex);
-	g_owned.push_back(OwnedBuffer{ static_cast<uint8_t *>(h), static_cast<uint8_t *>(d), bytes });
+	g_owned.push_back(OwnedBuffer{ static_cast<uint8_t *>(h), static_cast<uint8_t *>(d), bytes, 0u });
 	return h;
 }
 extern "C" void detexhipFreePixelBuffer(void *p) {
 	if (!p) return;
 	{
-		std::lock_guard<std::mutex> lock(g_owned_mutex);
-		size_t k = 0;
-		while (k < g_owned.size() && g_owned[k].host != p) k++;
+		std::unique_lock<std::mutex> lock(g_owned_mutex);
+		auto find = [&]() { size_t k = 0; while (k < g_owned.size() && g_owned[k].host != p) k++; return k; };
+		size_t k = find();
 		if (k == g_owned.size()) { detexSetErrorMessage("detexhipFreePixelBuffer: %p was not returned by detexhipAllocPixelBuffer", p); return; }
+		// a decode of another thread may be reading or writing the buffer right now (OwnedHold): wait for it -- a decode always ends, its
+		// waits are bounded -- rather than free memory under a running kernel; after ten seconds the buffer is LEAKED with a message
+		const bool idle = g_owned_idle.wait_for(lock, std::chrono::seconds(10), [&]() { k = find(); return k == g_owned.size() || g_owned[k].in_use == 0; });
+		if (k == g_owned.size()) return;			// (freed by another thread meanwhile)
+		if (!idle) { detexSetErrorMessage("detexhipFreePixelBuffer: %p is still in use by a decode after 10 s; not freed", p); return; }
 		g_owned.erase(g_owned.begin() + (long)k);
 	}
 	(void)hipHostFree(p);
 }
+// Test hook: the next `calls` host-pointer calls of the calling thread that reach a kernel launch return false right after it, as if the
+// runtime had failed there (the kernels themselves run on); what tests/ use to check that the call after a failed one starts clean.
+extern "C" void detexhipTestFailAfterLaunch(int calls) { t_fail_after_launch = calls > 0 ? calls : 0; }
 
 extern "C" void detexhipGetResidentStats(unsigned long long *requests, unsigned long long *instances) {
 	if (requests) *requests = t_ctx.service.served;
@@ -375,24 +446,37 @@ struct TextureCall {
 	// copy-out of the pinned exchange both disappear.  Larger textures take the staged path, whose download into pinned memory is the
 	// fastest copy there is.
 	Outcome via_owned_pixel_buffer() const {
-		if (tiled || out_bytes > Tune::kOwnedDirectBytes || in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
-		uint8_t *dev = owned_device_view(pixel_buffer, out_bytes);
+		if (tiled || out_bytes > Tune::kOwnedDirectBytes) return kNotTaken;
+		// (the kernels' row stores need the alignment the device tier asks for -- device_tier.cpp: palign; an odd sub-range of an owned buffer
+		// takes the copying paths like any other pointer)
+		const size_t palign = px == 3 ? 1 : (px < 4 ? px : 4);
+		if (reinterpret_cast<uintptr_t>(pixel_buffer) % palign != 0) return kNotTaken;
+		OwnedHold pixels_hold, blocks_hold;
+		uint8_t *dev = pixels_hold.acquire(pixel_buffer, out_bytes);
 		if (!dev) return kNotTaken;
+		// (the blocks may live in such a buffer too -- it is ordinary pinned memory: then the kernel reads them where they are, whatever
+		// their size; blocks that have to be copied into the exchange buffer first are limited like the staged path's pinned input)
+		const uint8_t *dev_blocks = reinterpret_cast<uintptr_t>(texture->data) % bs == 0 ? blocks_hold.acquire(texture->data, in_bytes) : nullptr;	// (a block is one 8 / 16-byte load)
+		if (!dev_blocks && in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
 		const int epi = prepared_epilogue(texture->format, pixel_format);
 		if (epi == -2) return kFalse;
-		// (the blocks may live in such a buffer too -- it is ordinary pinned memory: then the kernel reads them where they are)
-		const uint8_t *dev_blocks = reinterpret_cast<uintptr_t>(texture->data) % bs == 0 ? owned_device_view(texture->data, in_bytes) : nullptr;	// (a block is one 8 / 16-byte load)
 		DirectExchange x;
 		if (!direct_exchange(c, dev_blocks ? 0 : in_bytes, 0, &x)) return kFalse;
 		if (!dev_blocks) { memcpy(x.h_base + x.in_off, texture->data, in_bytes); dev_blocks = x.d_base + x.in_off; }
 		*reinterpret_cast<volatile uint32_t *>(x.h_base) = 0;
 		const uint32_t ticket = next_ticket(c);
 		bool empty = false;
+		c.dirty = true;
 		if (!launch_rows(epi, dev_blocks, dev, reinterpret_cast<uint32_t *>(x.d_base), 0, hb,
-				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket }, &empty)) return kFalse;
-		if (!empty && !wait_for_ticket(c, x, ticket)) return kFalse;
+				Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + kStatusBandCounters, ticket }, &empty)) return drained(kFalse);
+		if (injected_failure()) return drained(kFalse);
+		if (!empty && !wait_for_ticket(c, x, ticket)) return drained(kFalse);
+		c.dirty = false;
 		return *reinterpret_cast<volatile uint32_t *>(x.h_base) != 0 ? block_failed() : kTrue;
 	}
+	// A failure after a launch on a path whose kernel writes into memory that is NOT the thread context's (a held owned buffer): the holds
+	// are about to be dropped, so whatever is still running is waited for here (the context stays `dirty` for the next call to clean up).
+	Outcome drained(Outcome r) const { (void)hipStreamSynchronize(c.stream); (void)hipGetLastError(); return r; }
 
 	// Blocks + pixels up to Tune::kHostDirectBytes: the kernel reads the blocks from, and writes pixels and status into, pinned host memory
 	// (direct_exchange); the caller polls a completion word and copies the pixels out.  Above a quarter MiB of pixels the linear layout
@@ -409,8 +493,11 @@ struct TextureCall {
 		*h_status = 0;
 		uint32_t *d_st = reinterpret_cast<uint32_t *>(x.d_base);
 		if (tiled) {
+			c.dirty = true;
 			if (detexhipDecompressTextureTiledDevice(texture->format, x.d_base + x.in_off, (int)wb, (int)hb, x.d_base + x.out_off, pixel_format, c.stream, d_st) != 0) return kFalse;
+			if (injected_failure()) return kFalse;
 			if (hipStreamSynchronize(c.stream) != hipSuccess) { detexSetErrorMessage("libdetexhip: hipStreamSynchronize failed"); return kFalse; }
+			c.dirty = false;
 			copy_out(x.h_base + x.out_off);
 			return *h_status != 0 ? block_failed() : kTrue;
 		}
@@ -419,21 +506,24 @@ struct TextureCall {
 		const int bands = (out_bytes > ((size_t)256 << 10) && hb >= (size_t)(2 * kDirectBands)) ? kDirectBands : 1;
 		uint32_t tickets[kDirectBands];
 		size_t band_y1[kDirectBands];
+		c.dirty = true;
 		for (int b = 0; b < bands; b++) {
 			const size_t r0 = (size_t)b * hb / (size_t)bands, r1 = (size_t)(b + 1) * hb / (size_t)bands;
 			band_y1[b] = b + 1 == bands ? height : (r1 * 4u < height ? r1 * 4u : height);
 			tickets[b] = next_ticket(c);
 			bool empty = false;
 			if (!launch_rows(epi, x.d_base + x.in_off, x.d_base + x.out_off, d_st, r0, r1,
-					Completion{ reinterpret_cast<uint32_t *>(x.d_base + (bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)), c.d_status + 16 + b, tickets[b] }, &empty)) return kFalse;
+					Completion{ reinterpret_cast<uint32_t *>(x.d_base + (bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)), c.d_status + kStatusBandCounters + b, tickets[b] }, &empty)) return kFalse;
 			if (empty) tickets[b] = 0;
 		}
+		if (injected_failure()) return kFalse;
 		size_t y_done = 0;
 		for (int b = 0; b < bands; b++) {
 			if (tickets[b] != 0 && !wait_for_ticket(c, x, tickets[b], bands == 1 ? kDoneOffset : kBandDoneOffset + 16u * (size_t)b)) return kFalse;
 			copy_out_rows(x.h_base + x.out_off, y_done, band_y1[b]);
 			y_done = band_y1[b];
 		}
+		c.dirty = false;
 		return *h_status != 0 ? block_failed() : kTrue;
 	}
 
@@ -469,9 +559,11 @@ struct TextureCall {
 		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
 		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
 		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
+		c.dirty = true;
 		const int rc = tiled ? detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status)
 			: detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format, c.stream, d_status);
 		if (rc != 0) return kFalse;
+		if (injected_failure()) return kFalse;
 		if (tiled || (cov_w == width && cov_h == height)) {
 			if (!try_hip(hipMemcpyAsync(pixel_buffer, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
 		} else if (cov_w > 0 && cov_h > 0) {
@@ -479,10 +571,11 @@ struct TextureCall {
 		}
 		if (!pinned_status && !try_hip(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
 		if (!try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
-		if (*h_status == 0) return kTrue;
+		if (*h_status == 0) { c.dirty = false; return kTrue; }
 		if (!pinned_status) {		// (the device word is zero between calls: restore that before reporting)
 			if (!try_hip(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync") || !try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
 		}
+		c.dirty = false;
 		return block_failed();
 	}
 };
@@ -519,7 +612,7 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		return false;
 	}
 	if (out_bytes == 0 || wb * hb == 0) return true;
-	if (!context_ready()) return false;
+	if (!context_usable()) return false;
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
@@ -555,7 +648,7 @@ extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *text
 		detexSetErrorMessage("%s: format 0x%08X -> pixel format 0x%08X is outside the block-decode path of libdetexhip", who, format, pixel_format);
 		return false;
 	}
-	if (!context_ready()) return false;
+	if (!context_usable()) return false;
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
@@ -569,7 +662,7 @@ extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *text
 	}
 	if (!reserve(&c.d_in, &c.in_cap, in_total ? in_total : 256) || !reserve(&c.d_out, &c.out_cap, out_total ? out_total : 256)) return false;
 	detexhipLevel lv[kMaxLevels];
-	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	c.dirty = true;
 	for (int l = 0; l < n_textures; l++) {
 		const detexTexture *t = textures[l];
 		const size_t nbytes = (size_t)t->width_in_blocks * (size_t)t->height_in_blocks * bs;
@@ -578,13 +671,16 @@ extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *text
 			(size_t)t->width * px, t->width, t->height, t->width_in_blocks, t->height_in_blocks };
 	}
 	if (detexhipDecompressLevelsLinearDevice(format, lv, n_textures, pixel_format, c.stream, c.d_status) != 0) return false;
+	if (injected_failure()) return false;
 	uint32_t status = 0;
 	for (int l = 0; l < n_textures; l++) {
 		const size_t nbytes = (size_t)textures[l]->width * (size_t)textures[l]->height * px;
 		if (nbytes) HIP_TRY(hipMemcpyAsync(pixel_buffers[l], static_cast<uint8_t *>(c.d_out) + out_off[l], nbytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	}
 	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");		// (zero between calls)
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	c.dirty = false;
 	if (status != 0) {
 		detexSetErrorMessage("detexDecompressBlock: Decompress function for format 0x%08X returned error", format);
 		return false;
@@ -617,7 +713,7 @@ extern "C" bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t 
 		if (r == 0) { memset(pixels, 0, out_per_block); failed_text(); }
 		return r == 1;
 	}
-	if (!context_ready()) return false;
+	if (!context_usable()) return false;
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
@@ -636,9 +732,12 @@ extern "C" bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t 
 		const uint32_t ticket = next_ticket(c);
 		a.blocks = x.d_base + x.in_off; a.pixels = x.d_base + x.out_off; a.ok = x.d_base + x.out_off + ok_off;
 		a.status = reinterpret_cast<uint32_t *>(x.d_base);
-		a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + 16, ticket };
+		a.completion = Completion{ reinterpret_cast<uint32_t *>(x.d_base + kDoneOffset), c.d_status + kStatusBandCounters, ticket };
+		c.dirty = true;
 		HIP_TRY(f->blocks(a), "kernel launch");
+		if (injected_failure()) return false;
 		if (!wait_for_ticket(c, x, ticket)) return false;
+		c.dirty = false;
 		memcpy(pixels, x.h_base + x.out_off, out_bytes);
 		if (ok) memcpy(ok, x.h_base + x.out_off + ok_off, n_blocks);
 		if (*reinterpret_cast<volatile uint32_t *>(x.h_base) != 0) { failed_text(); return false; }
@@ -648,15 +747,18 @@ extern "C" bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t 
 	const size_t ok_off = (out_bytes + 255) & ~(size_t)255;
 	if (!reserve(&c.d_in, &c.in_cap, in_bytes) || !reserve(&c.d_out, &c.out_cap, ok_off + n_blocks)) return false;
 	uint8_t *d_out = static_cast<uint8_t *>(c.d_out);
-	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");
+	c.dirty = true;
 	HIP_TRY(hipMemcpyAsync(c.d_in, blocks, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
 	a.blocks = c.d_in; a.pixels = d_out; a.ok = d_out + ok_off; a.status = c.d_status;
 	HIP_TRY(f->blocks(a), "kernel launch");
+	if (injected_failure()) return false;
 	uint32_t status = 0;
 	HIP_TRY(hipMemcpyAsync(pixels, d_out, out_bytes, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	if (ok) HIP_TRY(hipMemcpyAsync(ok, d_out + ok_off, n_blocks, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	HIP_TRY(hipMemcpyAsync(&status, c.d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemsetAsync(c.d_status, 0, 4, c.stream), "hipMemsetAsync");		// (zero between calls)
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	c.dirty = false;
 	if (status != 0) { failed_text(); return false; }
 	return true;
 }
@@ -665,17 +767,20 @@ extern "C" bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t 
 extern "C" bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *blocks, size_t n_blocks, uint32_t histogram[16]) {
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("detexhipModeHistogram: 0x%08X is not a block-compressed format of this library", texture_format); return false; }
-	if (!context_ready()) return false;
+	if (!context_usable()) return false;
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
 	const size_t nbytes = n_blocks * detexGetCompressedBlockSize(texture_format);
 	if (!reserve(&c.d_in, &c.in_cap, nbytes ? nbytes : 256)) return false;
 	if (nbytes) HIP_TRY(hipMemcpyAsync(c.d_in, blocks, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
-	uint32_t *d_hist = c.d_status;		// 16 words (the status allocation is 64 bytes)
+	uint32_t *d_hist = c.d_status;		// words 0 .. kStatusHistogramBins - 1 of the status allocation, zeroed again below (the words are zero between calls)
+	c.dirty = true;
 	if (detexhipModeHistogramDevice(texture_format, c.d_in, n_blocks, d_hist, c.stream) != 0) return false;
-	HIP_TRY(hipMemcpyAsync(histogram, d_hist, 64, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemcpyAsync(histogram, d_hist, kStatusHistogramBins * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+	HIP_TRY(hipMemsetAsync(d_hist, 0, kStatusHistogramBins * sizeof(uint32_t), c.stream), "hipMemsetAsync");
 	HIP_TRY(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+	c.dirty = false;
 	return true;
 }
 

@@ -33,6 +33,11 @@ struct ProductTune {
 	static constexpr int kWorkgroupsPerCu = -1;
 	// memory-side cache of the device (MI355X: 256 MiB Infinity Cache): a texture whose blocks + pixels fit is not HBM-bound
 	static constexpr unsigned long kInfinityCacheBytes = 256ul << 20;
+	// Textures whose compressed blocks alone exceed that cache (32768^2 BC1: 512 MiB) are decoded in bands of block rows whose blocks fit
+	// this many bytes, each band's blocks first read into the cache by a read-only pass (histogram.hip: read_ahead) and then decoded:
+	// HBM sees a read phase and a write phase instead of reads scattered through the write stream (device_tier.cpp: linear_device_with;
+	// DESIGN.md section 4, "the large-footprint cliff")
+	static constexpr unsigned long kReadAheadBandBytes = 128ul << 20;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store

@@ -112,6 +112,8 @@ static inline uint32_t detexGetCompressedBlockSize(uint32_t texture_format) {
 	return 8 + ((texture_format & DETEX_TEXTURE_FORMAT_128BIT_BLOCK_BIT) >> 20);
 }
 static inline uint32_t detexFormatIsCompressed(uint32_t texture_format) { return (texture_format >> 24) != 0; }
+/* (detex.h:89, 906-909: bit 2 of a pixel or texture format = it has an alpha component; validate.c:202 picks BGRA8 or BGRX8 by it) */
+static inline uint32_t detexFormatHasAlpha(uint32_t format) { return (format & 0x4u) != 0; }
 static inline uint32_t detexGetPixelFormat(uint32_t texture_format) {
 	return texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK;
 }

@@ -43,10 +43,18 @@ DETEXHIP_API void detexhipReleaseThreadResources(void);
  * straight into it -- same call, same result, no copy-out (256x256: 20 -> 15 us, 512x512: 50 -> 31 us, 1024x1024: 118 -> 108-111 us per
  * call from compiled C; the first two are the PCIe floor); larger ones are
  * downloaded into it at the link's rate.  One allocation may hold many images (any sub-range works), and the compressed blocks as well
- * (texture->data inside such memory is read by the kernel where it is: one copy less).  Plain host memory otherwise: read
- * and write it like malloc'ed memory, free it with detexhipFreePixelBuffer only.  NULL + error message on failure.  Thread-safe. */
+ * (texture->data inside such memory is read by the kernel where it is, whatever its size: one copy less).  A sub-range that is not
+ * aligned to the target pixel (4 bytes for 32- and 64-bit pixels) is decoded through the copying paths, like any other pointer.
+ * Plain host memory otherwise: read and write it like malloc'ed memory, free it with detexhipFreePixelBuffer only.  NULL + error message
+ * on failure.  Thread-safe: a decode holds the buffers it reads or writes directly until its kernel has completed, and
+ * detexhipFreePixelBuffer WAITS for such decodes of other threads to end before it frees (if one has not ended after 10 s the buffer is
+ * left allocated and the error message says so). */
 DETEXHIP_API void *detexhipAllocPixelBuffer(size_t bytes);
 DETEXHIP_API void detexhipFreePixelBuffer(void *pixel_buffer);
+/* Test hook (tests/ only): the next `calls` host-pointer calls of the calling thread that launch a kernel return false right after the
+ * launch, as if the runtime had failed there.  A call that fails after it launched leaves the thread's device state to be cleaned up by
+ * the NEXT call (stream drained, status words zeroed): this is how the tests reach that path. */
+DETEXHIP_API void detexhipTestFailAfterLaunch(int calls);
 DETEXHIP_API const char *detexhipVersion(void);
 /* The extension API's structs grow now and then (detexhipShard gained `peer_access` in 0.3 -> ABI 4): a client passes the
  * DETEXHIP_ABI_VERSION it was COMPILED with and gets 0 if this library lays the structs out the same way, non-zero (and an error
@@ -233,6 +241,13 @@ DETEXHIP_API uint8_t detexhipHalfFloatToUNorm8(uint16_t half_bits);
 enum { DETEXHIP_QUIRK_BC7_MODE6_PBIT = 1, DETEXHIP_QUIRK_BC6H_MODE12_BIT63 = 2, DETEXHIP_QUIRKS_REFERENCE = 3 };
 DETEXHIP_API void detexhipSetQuirks(uint32_t quirks);
 DETEXHIP_API uint32_t detexhipGetQuirks(void);
+
+/* Textures whose compressed blocks exceed the GPU's 256 MiB memory-side cache (32768 x 32768 BC1: 512 MiB of blocks) are decoded by
+ * detexhipDecompressTextureLinearDevice in bands of block rows, each band's blocks (at most 128 MiB) read into that cache by a read-only
+ * pass before the band is decoded -- several launches on the caller's stream instead of one; same pixels, same status word.  HBM then sees
+ * a read phase and a write phase per band instead of reads scattered through the write stream.  On by default; 0 = always one launch
+ * (DETEXHIP_READ_AHEAD=0 in the environment does the same).  Per calling thread.  Returns the previous setting. */
+DETEXHIP_API int detexhipSetReadAhead(int on);
 
 /* Kernel-variant selection for A/B measurements (profiles/AB_RECORD.md).  The product library has ONE kernel per
  * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab:

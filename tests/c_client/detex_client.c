@@ -12,6 +12,11 @@
  *                                        detexDecompressTextureLinear on 64x64 ... 4096x4096 BC1 and BC7 textures: what a C caller pays,
  *                                        without the ctypes overhead bench.py's host_tier_small carries; `owned`: the pixel buffers come from
  *                                        detexhipAllocPixelBuffer (pinned: the kernel writes straight into them)
+ *   detex_client --oneshot[-breakdown] file.ktx ...   what a one-shot client pays (the reference's own callers decode their files once and
+ *                                        exit: validate.c:188-223, detex-convert.c:310): milliseconds from main() to the first decoded
+ *                                        texture and to the end of the whole file sequence, each file decoded ONCE into BGRA8 / BGRX8 like
+ *                                        validate.c:199-209; -breakdown (libdetexhip builds) times the runtime's initialisation separately
+ *                                        by asking for the device count first
  *   detex_client --blocks                n = 1, 1024, 1048576 independent blocks (BC1, BC7): the loop over the leaf function
  *                                        (detex.h:435-531) against ONE detexhipDecompressBlocks call (libdetexhip builds only:
  *                                        -DWITH_DETEXHIP), results compared block by block
@@ -160,6 +165,33 @@ static int latency(int owned) {
 	return wrong != 0;
 }
 
+/* validate.c:188-223 in a fresh process: every file loaded and decoded once (BGRA8 for formats with alpha, else BGRX8); the clock starts in main() */
+static int oneshot(int argc, char **argv, int breakdown, double t_main) {
+	double init_ms = -1.0, first_ms = -1.0, first_load_ms = -1.0;
+	int decoded = 0, refused = 0;
+	char hex[65] = "";
+#ifdef WITH_DETEXHIP
+	if (breakdown) { (void)detexhipGetDeviceCount(); init_ms = (now_us() - t_main) * 1e-3; }
+#else
+	(void)breakdown;
+#endif
+	for (int i = 0; i < argc; i++) {
+		detexTexture *texture = NULL;
+		if (!detexLoadKTXFile(argv[i], &texture)) { printf("oneshot ERROR %s: %s\n", argv[i], detexGetErrorMessage()); return 1; }
+		if (i == 0) first_load_ms = (now_us() - t_main) * 1e-3;
+		const uint32_t pixel_format = detexFormatHasAlpha(texture->format) ? DETEX_PIXEL_FORMAT_BGRA8 : DETEX_PIXEL_FORMAT_BGRX8;
+		const size_t bytes = (size_t)texture->width * (size_t)texture->height * 4u;
+		uint8_t *pixels = (uint8_t *)malloc(bytes);
+		if (detexDecompressTextureLinear(texture, pixels, pixel_format)) decoded++; else refused++;	/* (validate.c:210-214 prints and goes on) */
+		if (i == 0) { first_ms = (now_us() - t_main) * 1e-3; sha256_of(pixels, bytes, hex); }
+		free(pixels); free(texture->data); free(texture);
+	}
+	const double all_ms = (now_us() - t_main) * 1e-3;
+	printf("oneshot files=%d decoded=%d refused=%d init_ms=%.3f first_file_loaded_ms=%.3f first_call_ms=%.3f fixture_sequence_ms=%.3f first_sha256=%s\n", argc, decoded, refused,
+		init_ms, first_load_ms, first_ms, all_ms, hex);
+	return 0;
+}
+
 /* the migration of a per-block client: the loop over a leaf function against one batched call */
 static int blocks_mode(void) {
 	static const size_t counts[3] = { 1, 1024, 1048576 };
@@ -221,6 +253,9 @@ static int blocks_mode(void) {
 }
 
 int main(int argc, char **argv) {
+	const double t_main = now_us();
+	if (argc >= 3 && !strcmp(argv[1], "--oneshot")) return oneshot(argc - 2, argv + 2, 0, t_main);
+	if (argc >= 3 && !strcmp(argv[1], "--oneshot-breakdown")) return oneshot(argc - 2, argv + 2, 1, t_main);
 	if (argc >= 2 && !strcmp(argv[1], "--latency")) return latency(argc >= 3 && !strcmp(argv[2], "owned"));
 	if (argc >= 2 && !strcmp(argv[1], "--blocks")) return blocks_mode();
 	if (argc >= 2 && !strcmp(argv[1], "--sha256-selftest")) {

@@ -29,7 +29,7 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = binding.load()
     declared = _declared_symbols()
-    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 10 + 2 + 4) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device incl. the host-output entry, release, host aliases, half table, accumulating histogram, quirk switch, the two resident-service calls; round 5: the batched host-pointer block entry, the ABI check, the pixel-buffer allocator pair), data tables
+    assert len(declared) == (19 + 3 + 2 + 2) + (9 + 4 + 10 + 2 + 4 + 2) + 4, sorted(declared)   # detex.h, detexhip.h (+ multi-device incl. the host-output entry, release, host aliases, half table, accumulating histogram, quirk switch, the two resident-service calls; round 5: the batched host-pointer block entry, the ABI check, the pixel-buffer allocator pair; round 6: the fail-after-launch test hook, the read-ahead switch), data tables
     out = subprocess.check_output(["nm", "-D", "--defined-only", binding.LIB_PATH], text=True)
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert declared <= exported, sorted(declared - exported)

@@ -512,3 +512,149 @@ def test_library_owned_pixel_buffers_lifecycle(hiplib, oracle):
     for t in th: t.start()
     for t in th: t.join()
     assert not errors, errors
+
+
+# ---- round 6: lifetime and failure hazards of the host tier ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,W,H", [("BC1", 512, 512), ("BPTC_FLOAT", 256, 256), ("RGTC2", 300, 200)])
+def test_owned_pixel_buffer_at_odd_offsets(name, W, H, hiplib, oracle):
+    """a pixel buffer that lies inside library-owned memory but is NOT aligned to the target pixel (owned + 1, + 2, + 6): the kernel's row
+    stores cannot write there, so the call takes the copying paths like any other pointer -- same pixels, nothing outside the image touched"""
+    fmt = F.BY_NAME[name]
+    data = ol.stream_u(fmt, ((W + 3) // 4) * ((H + 3) // 4), seed=0x0DD + W)
+    n = W * H * fmt.pixel_bytes
+    want_ok, want = oracle.linear(fmt, data, W, H)
+    ptr, whole = _owned(hiplib.lib, n + 256)
+    try:
+        for off in (1, 2, 6, 64 + 3):
+            whole[:] = 0x5A
+            ok, got = hiplib.linear(fmt, data, W, H, out=whole[off:off + n])
+            assert ok == want_ok and np.array_equal(got, want), (name, off)
+            assert (whole[:off] == 0x5A).all() and (whole[off + n:] == 0x5A).all(), (name, off)
+    finally:
+        hiplib.lib.detexhipFreePixelBuffer(ptr)
+
+
+def test_free_of_an_owned_buffer_waits_for_the_decode_in_flight(hiplib, oracle):
+    """detexhipFreePixelBuffer from one thread while another thread's kernel is writing into that buffer: the free waits for the decode (the
+    decode holds the buffer from the lookup to its completion), the decode returns true with nothing lost, and the buffer is freed exactly
+    once -- 25 rounds, the free issued at varying moments after the decode call has started"""
+    import threading, time
+    lib = hiplib.lib
+    fmt = F.BY_NAME["BPTC"]
+    W = H = 1400                                                     # 7.5 MiB of pixels: the direct-write path, ~0.4 ms per call
+    data = ol.stream_u(fmt, 350 * 350, seed=0xF3EE).reshape(-1, 16)
+    data[:, 0] |= 1
+    data = data.reshape(-1)
+    _, want = oracle.linear(fmt, data, W, H)
+    want_sum = int(want.astype(np.uint64).sum())
+    results = []
+    for rnd in range(25):
+        ptr, view = _owned(lib, W * H * 4)
+        started = threading.Event()
+        seen = {}
+
+        def decoder():
+            api = ol.DetexAPI(hiplib.path)
+            api.linear(fmt, data, W, H, out=view)                     # (this thread's context exists before the timed call)
+            view[:] = 0
+            started.set()
+            ok, got = api.linear(fmt, data, W, H, out=view)
+            seen["returned"] = time.perf_counter()
+            seen["ok"] = ok
+        t = threading.Thread(target=decoder)
+        t.start()
+        started.wait()
+        time.sleep(0.00002 * (rnd % 8))                               # 0 .. 140 us into the call
+        lib.detexhipFreePixelBuffer(ptr)
+        freed = time.perf_counter()
+        t.join()
+        assert seen["ok"], hiplib.error()
+        results.append(freed - seen["returned"])
+        lib.detexSetErrorMessage(b"(none)")
+        lib.detexhipFreePixelBuffer(ptr)                              # freed exactly once
+        assert "was not returned by detexhipAllocPixelBuffer" in hiplib.error()
+    # and the memory is an ordinary pointer afterwards: a fresh owned buffer decodes correctly
+    ptr, view = _owned(lib, W * H * 4)
+    try:
+        ok, got = hiplib.linear(fmt, data, W, H, out=view)
+        assert ok and int(got.astype(np.uint64).sum()) == want_sum and np.array_equal(got, want)
+    finally:
+        lib.detexhipFreePixelBuffer(ptr)
+    print("free returned %.0f .. %.0f us relative to the decode's return" % (min(results) * 1e6, max(results) * 1e6))
+
+
+@pytest.mark.parametrize("path,name,W,H", [("leaf", "BPTC", 4, 4), ("pinned", "BPTC", 256, 256), ("banded", "BPTC", 512, 512), ("staged_pinned_status", "BPTC", 1024, 1024),
+                                           ("staged_device_status", "BPTC", 4100, 4096), ("owned", "BPTC", 1024, 1024), ("tiled_pinned", "BPTC", 256, 256),
+                                           ("blocks_direct", "BPTC", 0, 0), ("blocks_staged", "BPTC", 0, 0), ("histogram", "BPTC", 0, 0)])
+def test_call_after_a_failure_behind_the_launch_starts_clean(path, name, W, H, hiplib, oracle):
+    """detexhipTestFailAfterLaunch(1): the next call returns false right behind its kernel launch -- with invalid blocks in its input, so the
+    kernels it leaves running RAISE the status word, count on the completion counters and write into the pinned exchange buffer.  The
+    call after it (all blocks valid) must return true with the oracle's pixels on every host path: the thread's stream is drained and its
+    device words are zeroed before anything new is launched (host_tier.cpp: heal_if_dirty)."""
+    lib = hiplib.lib
+    lib.detexhipTestFailAfterLaunch.argtypes = [ctypes.c_int]
+    lib.detexhipTestFailAfterLaunch.restype = None
+    fmt = F.BY_NAME[name]
+    if path in ("blocks_direct", "blocks_staged", "histogram"):
+        n = 3000 if path == "blocks_direct" else (200000 if path == "blocks_staged" else 50000)
+        bad = ol.stream_u(fmt, n, seed=0xBADB10C)
+        good = bad.copy().reshape(-1, 16); good[:, 0] |= 1; good = good.reshape(-1)
+        if path == "histogram":
+            f = lib.detexhipModeHistogram
+            f.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            f.restype = ctypes.c_bool
+            hist = np.zeros(16, np.uint32)
+            assert f(fmt.texture_format, good.ctypes.data, n, hist.ctypes.data) and int(hist.sum()) == n
+            first = hist.copy()
+            lib.detexhipTestFailAfterLaunch(1)
+            ok, _, _ = hiplib.blocks(fmt, bad)                          # fails behind its launch, status word raised by the kernel
+            assert not ok and "injected failure" in hiplib.error()
+            assert f(fmt.texture_format, good.ctypes.data, n, hist.ctypes.data) and np.array_equal(hist, first)
+            return
+        lib.detexhipTestFailAfterLaunch(1)
+        ok, _, _ = hiplib.blocks(fmt, bad)
+        assert not ok and "injected failure" in hiplib.error()
+        ok, okb, px = hiplib.blocks(fmt, good)
+        assert ok and (okb == 1).all()
+        for i in (0, n // 2, n - 1):
+            _, want = oracle.linear(fmt, good[16 * i:16 * i + 16], 4, 4)
+            assert np.array_equal(px[i], want), (path, i)
+        return
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    bad = ol.stream_u(fmt, wb * hb, seed=0xFA11 + W)
+    bad[:16] = 0                                                      # the first block is reserved mode 8: invalid for sure
+    good = bad.copy().reshape(-1, 16); good[:, 0] |= 1; good = good.reshape(-1)
+    rows = min(hb, 8)
+    _, want_rows = oracle.linear(fmt, good[:rows * wb * 16], W, min(rows * 4, H))
+    owned = None
+    if path == "owned":
+        owned = _owned(lib, W * H * 4)
+
+    def call(data):
+        if path == "leaf":
+            return hiplib.block(fmt, data[:16])
+        if path == "tiled_pinned":
+            return hiplib.tiled(fmt, data, wb, hb)
+        return hiplib.linear(fmt, data, W, H, out=owned[1] if owned else None)
+    try:
+        for rnd in range(2):
+            lib.detexhipTestFailAfterLaunch(1)
+            ok, _ = call(bad)
+            assert not ok and "injected failure" in hiplib.error(), (path, rnd, hiplib.error())
+            ok, got = call(good)
+            assert ok, (path, rnd, hiplib.error())
+            if path == "leaf":
+                _, want = oracle.linear(fmt, good[:16], 4, 4)
+                assert np.array_equal(got, want)
+            elif path == "tiled_pinned":
+                _, want = oracle.linear(fmt, good[:16], 4, 4)
+                assert np.array_equal(got[:64], want)
+            else:
+                assert np.array_equal(got[:want_rows.size], want_rows), (path, rnd)
+            ok, _ = call(bad)                                         # and the status still works afterwards
+            assert not ok and (path == "leaf" or "returned error" in hiplib.error())   # (the leaf functions set no message: decompress-*.c)
+            ok, _ = call(good)
+            assert ok
+    finally:
+        if owned:
+            lib.detexhipFreePixelBuffer(owned[0])
