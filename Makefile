@@ -66,6 +66,17 @@ $(OBJDIR)/api_san_main.o: tests/host_san/api_san_main.cpp include/detex.h includ
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 tests/host_san/api_san: $(OBJDIR)/api_san_main.o $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -o $@ $^
+# thread / process / dlclose teardown of the host tier's per-thread state under the same sanitizers (tests/host_san/teardown_san_main.cpp):
+# the test main linked with the instrumented objects, and the same objects as a shared library for its dlclose mode
+teardown-san:
+	$(MAKE) tests/host_san/teardown_san tests/host_san/libdetexhip_san.so OBJDIR=build/obj_san EXTRA_HIPFLAGS="$(SANFLAGS)"
+$(OBJDIR)/teardown_san_main.o: tests/host_san/teardown_san_main.cpp include/detex.h include/detexhip.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DTEARDOWN_SAN_LINKED -c -o $@ $<
+tests/host_san/teardown_san: $(OBJDIR)/teardown_san_main.o $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -pthread -o $@ $^ -ldl
+tests/host_san/libdetexhip_san.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -shared -fPIC -o $@ $^
 
 # a plain C client of the drop-in boundary (tests/c_client/detex_client.c; tests/test_c_client.py runs it on the GPU box): gcc, this
 # repository's detex.h, -ldetexhip with an rpath to the library; where the reference's sources are present (build container) a second
@@ -85,6 +96,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/big_footprint tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san tests/host_san/teardown_san tests/host_san/libdetexhip_san.so $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/big_footprint tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib lib-ab api-san c-client oracle ubench hbmref clean
+.PHONY: all lib lib-ab api-san teardown-san c-client oracle ubench hbmref clean

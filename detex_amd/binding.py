@@ -44,6 +44,8 @@ def load():
     lib.detexhipKernelName.argtypes = [ctypes.c_uint32]
     lib.detexhipSetDevice.argtypes = [ctypes.c_int]
     lib.detexhipSetKernelVariant.argtypes = [ctypes.c_int]
+    lib.detexhipSetReadAhead.argtypes = [ctypes.c_int]
+    lib.detexhipSetReadAhead.restype = ctypes.c_int
     lib.detexhipSetResidentIdleMicroseconds.argtypes = [ctypes.c_int]
     lib.detexhipSetResidentIdleMicroseconds.restype = ctypes.c_int
     lib.detexhipGetResidentStats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
@@ -71,6 +73,11 @@ def _check(rc, what):
 
 def set_kernel_variant(v):
     load().detexhipSetKernelVariant(int(v))
+
+
+def set_read_ahead(on):
+    """detexhipSetReadAhead: the banded read-ahead of textures whose blocks exceed the Infinity Cache (on by default); returns the previous setting"""
+    return load().detexhipSetReadAhead(1 if on else 0)
 
 
 def set_resident_idle_us(us):

@@ -43,10 +43,10 @@ int epilogue_for(uint32_t texture_format, uint32_t pixel_format) {
 }
 bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) { return epilogue_for(texture_format, pixel_format) >= 0; }
 
-int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format) {
+int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format, hipStream_t stream) {
 	const int epi = epilogue_for(texture_format, pixel_format);
 	if ((texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK) == DETEX_PIXEL_FORMAT_FLOAT_RGBX16 && epi >= kEpiToRGBX8) {
-		hipError_t e = ensure_half_table();
+		hipError_t e = ensure_half_table(stream);
 		if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: half-float table upload failed: %s", hipGetErrorString(e)); return -2; }
 	}
 	return epi;
@@ -122,7 +122,7 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 		return 1;
 	}
 	if (!stream_on_current_device(static_cast<hipStream_t>(stream), "detexhipDecompressTextureLinearDevice")) return 1;
-	const int epi = prepared_epilogue(texture_format, pixel_format);
+	const int epi = prepared_epilogue(texture_format, pixel_format, static_cast<hipStream_t>(stream));
 	if (epi == -2) return 1;
 	Geometry g{ d_blocks, d_pixels, (uint32_t)width_in_blocks, (uint32_t)height_in_blocks, (uint32_t)width, (uint32_t)height,
 		(uint64_t)pitch_bytes, d_status, static_cast<hipStream_t>(stream), variant, epi, decode_flags, f->resident };
@@ -226,7 +226,7 @@ extern "C" int detexhipDecompressTextureTiledDevice(uint32_t texture_format, con
 	}
 	if (width_in_blocks < 0 || height_in_blocks < 0) { detexSetErrorMessage("detexhipDecompressTextureTiledDevice: bad geometry"); return 1; }
 	if (!stream_on_current_device(static_cast<hipStream_t>(stream), "detexhipDecompressTextureTiledDevice")) return 1;
-	const int epi = lookup_format(texture_format) ? prepared_epilogue(texture_format, pixel_format) : kEpiNone;
+	const int epi = lookup_format(texture_format) ? prepared_epilogue(texture_format, pixel_format, static_cast<hipStream_t>(stream)) : kEpiNone;
 	if (epi == -2) return 1;
 	return blocks_device("detexhipDecompressTextureTiledDevice", texture_format, d_blocks,
 		(size_t)width_in_blocks * (size_t)height_in_blocks, DETEX_MODE_MASK_ALL, 0, d_pixels, nullptr, d_status, stream, false, epi);
@@ -245,7 +245,7 @@ extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, con
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("%s: 0x%08X is not a block-compressed format of this library", who, texture_format); return 1; }
 	if (!stream_on_current_device(static_cast<hipStream_t>(stream), who)) return 1;
-	const int epi = prepared_epilogue(texture_format, pixel_format);
+	const int epi = prepared_epilogue(texture_format, pixel_format, static_cast<hipStream_t>(stream));
 	if (epi == -2) return 1;
 	if (epi < 0) { detexSetErrorMessage("%s: pixel format 0x%08X is outside the block-decode path for format 0x%08X", who, pixel_format, texture_format); return 1; }
 	if (n_levels < 0 || n_levels > kMaxLevels || (n_levels > 0 && !levels)) { detexSetErrorMessage("%s: 0..%d levels per call", who, kMaxLevels); return 1; }

@@ -47,7 +47,10 @@ uint8_t half_to_u8_entry(uint32_t h) {
 }
 static std::mutex g_half_table_mutex;
 static bool g_half_table_ready[64];
-hipError_t ensure_half_table() {
+// (uploaded on `stream` and waited for there -- not through hipMemcpyToSymbol, which goes through the NULL stream: in a process that
+// has used no other stream of its own that is one more hardware queue to create, 13 of the 16 ms this call took in the one-shot client's
+// API trace, profiles/r06/oneshot/)
+hipError_t ensure_half_table(hipStream_t stream) {
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
@@ -57,9 +60,12 @@ hipError_t ensure_half_table() {
 	static uint8_t table[65536];
 	static bool built = false;
 	if (!built) { for (uint32_t h = 0; h < 65536u; h++) table[h] = half_to_u8_entry(h); built = true; }
-	e = hipMemcpyToSymbol(HIP_SYMBOL(kHalfToU8), table, sizeof table, 0, hipMemcpyHostToDevice);
-	if (e == hipSuccess) g_half_table_ready[dev] = true;
-	return e;
+	void *d_table = nullptr;
+	if ((e = hipGetSymbolAddress(&d_table, HIP_SYMBOL(kHalfToU8))) != hipSuccess) return e;
+	if ((e = hipMemcpyAsync(d_table, table, sizeof table, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+	if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+	g_half_table_ready[dev] = true;
+	return hipSuccess;
 }
 
 }  // namespace detexhip

@@ -78,9 +78,10 @@ const FormatEntry *lookup_format(uint32_t texture_format);		// nullptr: not a bl
 // ---- target pixel formats (device_tier.cpp) ----------------------------------------------------------------------------------
 int epilogue_for(uint32_t texture_format, uint32_t pixel_format);	// kEpi..., -1 = not offered
 bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format);
-// epilogue for an accepted pair with its device table in place on the CURRENT device (-2 + error message if the upload failed)
-int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format);
-hipError_t ensure_half_table();						// formats_bptc_float.hip
+// epilogue for an accepted pair with its device table in place on the CURRENT device (-2 + error message if the upload failed); the
+// first use on a device uploads the table on `stream` (the one the caller is about to launch on) and waits for it
+int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format, hipStream_t stream);
+hipError_t ensure_half_table(hipStream_t stream);			// formats_bptc_float.hip
 uint8_t half_to_u8_entry(uint32_t half_bits);				// formats_bptc_float.hip (host function)
 bool stream_on_current_device(hipStream_t stream, const char *who);
 

@@ -248,7 +248,7 @@ int decode_one_block(const FormatEntry *f, const uint8_t *bitstring, uint32_t mo
 	const size_t bs = detexGetCompressedBlockSize(f->texture_format);
 	const size_t out_bytes = 16u * (size_t)detexGetPixelSize(pixel_format);
 	const uint32_t decode_flags = (flags & 0x3FFFFFFFu) | current_spec_flags();
-	const int epi = prepared_epilogue(f->texture_format, pixel_format);
+	const int epi = prepared_epilogue(f->texture_format, pixel_format, c.stream);
 	if (epi == -2) return -1;
 	if (c.service.wanted(f, epi)) {		// from the second call in a row on: a request to the resident kernel instead of a launch
 		uint32_t payload[12] = {};
@@ -422,7 +422,7 @@ struct TextureCall {
 			(void)c.service.wanted(nullptr, -1);
 			return kNotTaken;
 		}
-		const int epi = prepared_epilogue(texture->format, pixel_format);
+		const int epi = prepared_epilogue(texture->format, pixel_format, c.stream);
 		if (epi == -2) return kFalse;
 		if (!c.service.wanted(f, epi)) return kNotTaken;
 		// (up to one tile: the blocks travel as tagged chunks the kernel reads along with its polls -- path_types.h: kResidentTagged)
@@ -458,7 +458,7 @@ struct TextureCall {
 		// their size; blocks that have to be copied into the exchange buffer first are limited like the staged path's pinned input)
 		const uint8_t *dev_blocks = reinterpret_cast<uintptr_t>(texture->data) % bs == 0 ? blocks_hold.acquire(texture->data, in_bytes) : nullptr;	// (a block is one 8 / 16-byte load)
 		if (!dev_blocks && in_bytes > Tune::kHostPinnedInputBytes) return kNotTaken;
-		const int epi = prepared_epilogue(texture->format, pixel_format);
+		const int epi = prepared_epilogue(texture->format, pixel_format, c.stream);
 		if (epi == -2) return kFalse;
 		DirectExchange x;
 		if (!direct_exchange(c, dev_blocks ? 0 : in_bytes, 0, &x)) return kFalse;
@@ -501,7 +501,7 @@ struct TextureCall {
 			copy_out(x.h_base + x.out_off);
 			return *h_status != 0 ? block_failed() : kTrue;
 		}
-		const int epi = prepared_epilogue(texture->format, pixel_format);
+		const int epi = prepared_epilogue(texture->format, pixel_format, c.stream);
 		if (epi == -2) return kFalse;
 		const int bands = (out_bytes > ((size_t)256 << 10) && hb >= (size_t)(2 * kDirectBands)) ? kDirectBands : 1;
 		uint32_t tickets[kDirectBands];
@@ -622,10 +622,8 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 		// grid is smaller than the image, the rest of the caller's buffer is left untouched, not overwritten with staging bytes.
 		tiled ? 0 : (width < 4u * wb ? width : 4u * wb), tiled ? 0 : (height < 4u * hb ? height : 4u * hb) };
 	// by size: the resident service (up to 1024 blocks, from the second call in a row on), a pixel buffer the library handed out (written
-	// directly, up to 8 MiB), the pinned exchange (up to 1.25 MiB in all), staging through device memory.  (Round 5 also built a fourth path -- the caller's pixel buffer registered with the runtime for the call,
-	// the kernel writing straight into it: 512^2 50.5 -> 41.1 us -- and took it out again: the third full test run with it ended in a GPU memory
-	// access fault at a host heap address during a LATER, unrelated copy of the same process.  Registering memory the library does not own,
-	// which its owner then frees, is not something this tier can make safe: profiles/r05/host_registered_output_fault.txt.)
+	// directly, up to 8 MiB), the pinned exchange (up to 1.25 MiB in all), staging through device memory.  (The caller's OWN buffer is never
+	// registered with the runtime: its lifetime is not the library's to know -- DESIGN.md section 5.)
 	Outcome r = call.via_resident_service();
 	if (r == kNotTaken) r = call.via_owned_pixel_buffer();
 	if (r == kNotTaken) r = call.via_pinned_exchange();

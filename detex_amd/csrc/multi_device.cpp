@@ -149,7 +149,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDevice(uint32_t texture_forma
 		hipError_t e = prepare_slot(sl, sh.device);
 		if (e != hipSuccess) { fail("device / stream setup", e); break; }
 		sl.used = true;
-		if (prepared_epilogue(texture_format, pixel_format) == -2) { rc = 1; break; }	// the half-float table of THIS device
+		if (prepared_epilogue(texture_format, pixel_format, sl.stream) == -2) { rc = 1; break; }	// the half-float table of THIS device
 		if ((e = hipMemsetAsync(sl.d_status, 0, 4, sl.stream)) != hipSuccess) { fail("hipMemsetAsync", e); break; }
 		const size_t n = (size_t)(sh.row1 - sh.row0) * wb * bs;
 		if (!sh.d_blocks) {
@@ -261,7 +261,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 		ShardSlot &sl = slots.slot[g];
 		hipError_t e = prepare_slot(sl, devices[g]);
 		if (e != hipSuccess) { fail("device / stream setup", e); return; }
-		if (prepared_epilogue(texture_format, pixel_format) == -2) { snprintf(w.message, sizeof w.message, "%s: shard %d: conversion table upload failed", who, g); w.rc = 1; return; }
+		if (prepared_epilogue(texture_format, pixel_format, sl.stream) == -2) { snprintf(w.message, sizeof w.message, "%s: shard %d: conversion table upload failed", who, g); w.rc = 1; return; }
 		const size_t n_in = (size_t)(row1 - row0) * wb * bs, rows = y1 - y0;
 		if ((e = grow(&sl.d_upload, &sl.upload_cap, n_in)) != hipSuccess || (e = grow(&sl.d_band, &sl.band_cap, rows * row_bytes)) != hipSuccess) { fail("hipMalloc", e); return; }
 		if ((e = hipMemsetAsync(sl.d_status, 0, 4, sl.stream)) != hipSuccess) { fail("hipMemsetAsync", e); return; }

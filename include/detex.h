@@ -123,7 +123,10 @@ static inline uint32_t detexGetPixelFormat(uint32_t texture_format) {
  * One 8/16-byte block -> 16 pixels of the format's native pixel size, row-major.  Returns
  * false for a mode excluded by mode_mask, an opaque/non-opaque/encode filter in flags, or an
  * invalid block; pixel_buffer is then left untouched.
- * libdetexhip runs these on the GPU as well (one-block launch, two small copies). */
+ * libdetexhip runs these on the GPU as well: the block travels as a kernel argument, the pixels come back through a pinned
+ * exchange buffer whose completion word the caller polls (7 us), and from the second call in a row of one format on the
+ * request goes to a kernel that is already resident (5-6 us).  The reference needs 0.03-0.1 us: a client that decodes many
+ * blocks calls detexhipDecompressBlocks (detexhip.h) ONCE instead of looping here. */
 #define DETEXHIP_DECLARE_BLOCK_FN(NAME) \
 	DETEX_API bool detexDecompressBlock##NAME(const uint8_t *bitstring, uint32_t mode_mask, uint32_t flags, \
 		uint8_t *pixel_buffer);
@@ -149,9 +152,13 @@ DETEXHIP_DECLARE_BLOCK_FN(EAC_SIGNED_RG11)	/* decompress-eac.c:217 */
 #undef DETEXHIP_DECLARE_BLOCK_FN
 
 /* ---- generic block + whole-texture drivers (detex.h:747-765, texture.c:55-145) ---------
- * pixel_format must be the format's native pixel format or, for RGBX8/RGBA8 natives, either
- * of the two (the reference's no-op conversion edge, convert.c:768-769); any other target is
- * outside the block-decode path: the call returns false with an error message and the
+ * pixel_format: the format's native pixel format; for RGBX8 / RGBA8 natives either of the two (the
+ * reference's no-op conversion edge, convert.c:768-769); and the targets the reference's callers ask for,
+ * converted inside the decode kernel with the exact result of detexConvertPixels' path (convert.c:885-1063) --
+ * BGRA8 / BGRX8 (validate.c:204-209, detex-view.c:182), RGB8 (detex-convert.c:283-284), RGBA8 / RGBX8 for the
+ * one- and two-component and half-float formats, FLOAT_BGRX16 for BPTC_FLOAT -- for every format the reference
+ * itself can convert to them (all but BPTC_SIGNED_FLOAT; the signed 16-bit formats have no path to BGRA8).
+ * Any other target is outside the block-decode path: the call returns false with an error message and the
  * texture drivers zero-fill the output. */
 DETEX_API bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_format, uint32_t mode_mask,
 	uint32_t flags, uint8_t *pixel_buffer, uint32_t pixel_format);	/* texture.c:55 */

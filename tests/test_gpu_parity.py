@@ -391,7 +391,7 @@ def test_full_size_digest(name, torch_cuda, golden_json):
     fmt = F.BY_NAME[name]
     dg = golden_json("digests_8192.json")
     W, H = dg["width"], dg["height"]
-    kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT") else []) + (["C"] if fmt.fixture else [])
+    kinds = ["U"] + (["M"] if name in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT") else []) + (["C"] if fmt.fixture else [])
     for kind in kinds:                              # U uniform random, M modes equiprobable, C the bundled fixture tiled
         g = dg["streams"]["%s/%s" % (name, kind)]   # native target; epilogue targets: test_full_size_digest_epilogue_targets
         data = streams.make_stream(kind, fmt, W // 4, H // 4)
@@ -593,6 +593,45 @@ def test_maximum_size_texture(torch_cuda, oracle):
         got = out[r0 * 4 * W * fmt.pixel_bytes:(r0 + rows) * 4 * W * fmt.pixel_bytes].cpu().numpy()
         assert np.array_equal(got, want), (name, r0)
     del d, out
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["BC1", "BPTC_FLOAT"])
+def test_whole_32768_image_in_one_call_banded_read_ahead(name, torch_cuda, golden_json):
+    """the WHOLE 32768^2 image of the sharded configurations through ONE detexhipDecompressTextureLinearDevice call.  Its blocks (512 MiB /
+    1 GiB) exceed the 256 MiB Infinity Cache, so the entry decodes it in bands of <= 128 MiB of blocks, each read into that cache by a
+    read-only pass first (device_tier.cpp; detexhipSetReadAhead, on by default): every one of the eight eighths of the image digests to the
+    compiled reference's sha256 (tools/make_goldens.py bands_all), the status word is the reference's result, and the same call with the
+    read-ahead switched off (one launch) writes the identical image"""
+    from detex_amd import binding, sharding
+    torch = torch_cuda
+    fmt = F.BY_NAME[name]
+    side = 32768
+    gold = golden_json("digests_8192.json")["bands_all"]
+    whole = sharding.shard_of(0, 1, fmt, side, side)
+    data = ol.stream_u_slice(fmt, 0, whole.in_bytes // fmt.block_bytes)
+    d = _dev(torch, data)
+    del data
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert binding.set_read_ahead(True) in (0, 1)
+    try:
+        out = binding.decompress_linear_device(fmt, d, side, side, status=status)
+        torch.cuda.synchronize()
+        all_ok = True
+        for e in range(8):
+            g = gold["%s/%d/%dof8" % (name, side, e)]
+            piece = out[e * g["bytes"]:(e + 1) * g["bytes"]]
+            assert sha(piece.cpu().numpy()) == g["sha256"], (name, "eighth", e)
+            all_ok = all_ok and g["ok"]
+        assert bool(status.item() == 0) == all_ok
+        binding.set_read_ahead(False)
+        status2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out2 = binding.decompress_linear_device(fmt, d, side, side, status=status2)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2) and status.item() == status2.item()
+    finally:
+        binding.set_read_ahead(True)
+    del d, out, out2
     torch.cuda.empty_cache()
 
 

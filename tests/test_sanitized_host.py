@@ -104,3 +104,19 @@ def test_host_tier_under_sanitizers_on_the_gpu_box():
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout and "device part ran" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["threads", "exit", "dlclose"])
+def test_thread_and_process_teardown_under_sanitizers(mode):
+    """tests/host_san/teardown_san_main.cpp (`make teardown-san`, built by __graft_entry__.build()): threads decode through the host tier --
+    their resident service kernels alive, idle time 200 ms -- and exit WITHOUT detexhipReleaseThreadResources(); the process then returns
+    from main() with the main thread's resident kernel lingering (`threads`), leaves through exit() from a worker thread (`exit`), or
+    dlclose()s the instrumented library, opens and uses it again (`dlclose`).  No crash, no hang, no AddressSanitizer / UBSan report."""
+    exe = os.path.join(SAN, "teardown_san")
+    lib = os.path.join(SAN, "libdetexhip_san.so")
+    if not os.path.exists(exe) or not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "teardown-san"], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe, mode] + ([lib] if mode == "dlclose" else []), capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "teardown_san: ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-4000:])

@@ -68,7 +68,7 @@ def main():
               "reference_build": open(os.path.join(ROOT, "oracle/_ref/BUILD_INFO.txt")).read().strip(), "streams": {}}
         for f in F.FORMATS:
             for kind in ("U", "M"):
-                if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT"): continue
+                if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT"): continue
                 data = ol.stream_u(f, (W // 4) * (H // 4))
                 if kind == "M": data = streams.stream_m(f, data)
                 t = time.time(); ok, out = ref_linear_mt(ref, f, data, W, H); dt = time.time() - t
@@ -77,6 +77,14 @@ def main():
                 print(f.name, kind, ok, "%016x" % fnv, "%.2fs" % dt, flush=True)
     else:
         dg = json.load(open(dpath))
+    if "digests_m_signed" in sections and "BPTC_SIGNED_FLOAT/M" not in dg["streams"]:
+        # (round 6: stream M of the signed BC6H format added to an existing file without regenerating the other 40 digests)
+        f = F.BY_NAME["BPTC_SIGNED_FLOAT"]
+        data = streams.stream_m(f, ol.stream_u(f, (W // 4) * (H // 4)))
+        ok, out = ref_linear_mt(ref, f, data, W, H)
+        fnv = orc.lib.orc_fnv1a64(out.ctypes.data, out.size)
+        dg["streams"]["BPTC_SIGNED_FLOAT/M"] = {"ok": ok, "sha256": sha(out), "fnv1a64": "%016x" % fnv, "in_sha256": sha(data)}
+        print(f.name, "M", ok, "%016x" % fnv, flush=True)
     if "digests_c" in sections:
         # stream C: the bundled 64x64 fixture tiled over 8192^2 (tests/streams.py stream_c)
         for f in F.FORMATS:
