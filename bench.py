@@ -382,6 +382,38 @@ def main():
             got = self.d_out[:want.size].cpu().numpy()
             return rows * 4 if np.array_equal(got, want) else 0
 
+    class RotatingInputs:
+        """the same decode over R DIFFERENT input buffers in turn (R x blocks > 2.5 x the 256 MiB Infinity Cache), one output image: every
+        launch's blocks come out of HBM -- the regime of a stream of different textures.  (A loop over ONE input re-reads its blocks from
+        that memory-side cache: HBM then sees the writes only, and `frac` counts bytes HBM never delivered -- DESIGN.md section 4.)"""
+        def __init__(self, job):
+            self.job = job
+            n = int(job.d_blocks.numel())
+            self.inputs = [job.d_blocks] + [torch.roll(job.d_blocks, 4096 * k) for k in range(1, max(3, -(-(640 << 20) // n)))]
+            self.k = 0
+            self.blocks, self.alg_bytes, self.tpx, self.W, self.H = job.blocks, job.alg_bytes, job.tpx, job.W, job.H
+
+        def step(self):
+            j = self.job
+            self.k = (self.k + 1) % len(self.inputs)
+            binding.decompress_linear_device(j.fmt, self.inputs[self.k], j.W, j.H, out=j.d_out, status=j.status, pixel_format=j.pf)
+
+    def blocks_from_hbm_row(job):
+        """launch time with the blocks coming out of HBM (rotating inputs), as shipped and with the read-ahead pass forced (detexhipSetReadAhead(2))"""
+        rot = RotatingInputs(job)
+        us, _ = steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
+        row = {"inputs": len(rot.inputs), "launch_us": round(us, 2), "frac": round(job.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+        binding.set_read_ahead(2)
+        try:
+            us2, _ = steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
+        finally:
+            binding.set_read_ahead(1)
+        row["read_ahead_forced_launch_us"] = round(us2, 2)
+        row["read_ahead_forced_frac"] = round(job.alg_bytes / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+        del rot
+        torch.cuda.empty_cache()
+        return row
+
     def timed(job, steps, warmup):
         """the contract's timed region: W warm-up launches, then exactly K launches between barriers; wall = max over ranks"""
         for _ in range(warmup):
@@ -692,6 +724,15 @@ def main():
             result["roofline"].update(t)
         ref = hbm_reference(job)
         result["roofline"].update(ref)
+        if args.layout == "linear":
+            try:
+                result["roofline"]["blocks_from_hbm"] = dict(blocks_from_hbm_row(job), note=(
+                    "the timed loop decodes ONE input again and again: its %d MiB of blocks are re-read from the 256 MiB memory-side Infinity Cache (which the L2's "
+                    "EA counters behind `traffic` count as memory requests), HBM itself sees the pixel writes (`write_frac`).  Here the same launch over R different "
+                    "inputs in turn, so that every launch's blocks come out of HBM; read_ahead_forced_*: with detexhipSetReadAhead(2) -- a read-only pass over the blocks, "
+                    "then the decode" % (job.blocks * fmt.block_bytes >> 20)))
+            except Exception as e:  # noqa
+                log("blocks_from_hbm failed:", e)
         write_gbps = job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9
         result["roofline"]["write_GBps"] = round(write_gbps, 1)
         best_fill = max(ref.get("ref_fill_same_shape_GBps", 0), ref.get("ref_fill_GBps", 0), ref.get("ref_fill_torch_GBps", 0))
@@ -755,6 +796,11 @@ def main():
                 tr = pmc_traffic("%s/8192/linear" % name)
                 if tr and kind == "U":
                     row["traffic"] = tr["hbm_bytes_per_launch"]
+                if kind == "U":
+                    try:
+                        row["blocks_from_hbm"] = blocks_from_hbm_row(j)
+                    except Exception as e:  # noqa
+                        log("blocks_from_hbm failed:", name, e)
                 table["%s/%s" % (name, kind)] = row
                 del j
         for name, kind, layout in WEAK_KERNELS:

@@ -75,9 +75,10 @@ def set_kernel_variant(v):
     load().detexhipSetKernelVariant(int(v))
 
 
-def set_read_ahead(on):
-    """detexhipSetReadAhead: the banded read-ahead of textures whose blocks exceed the Infinity Cache (on by default); returns the previous setting"""
-    return load().detexhipSetReadAhead(1 if on else 0)
+def set_read_ahead(mode):
+    """detexhipSetReadAhead: 0 never, 1 (default; True) textures whose blocks exceed the Infinity Cache, 2 every texture with >= 1 MiB of blocks;
+    returns the previous mode"""
+    return load().detexhipSetReadAhead(int(mode))
 
 
 def set_resident_idle_us(us):

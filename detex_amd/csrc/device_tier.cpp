@@ -95,10 +95,12 @@ uint32_t current_spec_flags() {
 
 // Read-ahead of the blocks of textures beyond the Infinity Cache (linear_device_with): on unless switched off for the calling thread
 // (detexhipSetReadAhead, or DETEXHIP_READ_AHEAD=0 in the environment when the thread first decodes)
-bool current_read_ahead() {
+// 0 = never, 1 = textures whose blocks exceed the Infinity Cache (default), 2 = every texture with at least 1 MiB of blocks (a caller
+// who knows its blocks are NOT in that cache: freshly produced input, a stream of different textures)
+int current_read_ahead() {
 	ThreadSettings &s = t_settings;
-	if (s.read_ahead < 0) { const char *env = getenv("DETEXHIP_READ_AHEAD"); s.read_ahead = env ? (atoi(env) != 0) : 1; }
-	return s.read_ahead != 0;
+	if (s.read_ahead < 0) { const char *env = getenv("DETEXHIP_READ_AHEAD"); s.read_ahead = env ? atoi(env) : 1; if (s.read_ahead < 0 || s.read_ahead > 2) s.read_ahead = 1; }
+	return s.read_ahead;
 }
 
 int linear_device_with(uint32_t texture_format, const void *d_blocks, int width, int height, int width_in_blocks, int height_in_blocks,
@@ -137,7 +139,10 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 	// band's blocks read into the cache by a read-only pass first: a read phase and a write phase per band, on the caller's stream.
 	const size_t bs = detexGetCompressedBlockSize(texture_format), row_bytes = (size_t)width_in_blocks * bs;
 	const bool whole_grid = (size_t)width_in_blocks * 4u == (size_t)width && (size_t)height_in_blocks * 4u == (size_t)height;
-	if (current_read_ahead() && whole_grid && row_bytes * (size_t)height_in_blocks > Tune::kInfinityCacheBytes && row_bytes > 0 && row_bytes <= Tune::kReadAheadBandBytes) {
+	const int read_ahead = current_read_ahead();
+	const size_t block_bytes_total = row_bytes * (size_t)height_in_blocks;
+	if (whole_grid && row_bytes > 0 && row_bytes <= Tune::kReadAheadBandBytes &&
+			((read_ahead == 1 && block_bytes_total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && block_bytes_total >= ((size_t)1 << 20)))) {
 		const uint32_t band_rows = (uint32_t)(Tune::kReadAheadBandBytes / row_bytes);
 		for (uint32_t r0 = 0; r0 < (uint32_t)height_in_blocks; r0 += band_rows) {
 			const uint32_t rows = r0 + band_rows < (uint32_t)height_in_blocks ? band_rows : (uint32_t)height_in_blocks - r0;
@@ -179,7 +184,7 @@ extern "C" int detexhipCheckAbi(int compiled_against) {
 extern "C" void detexhipSetQuirks(uint32_t quirks) { thread_settings().quirks = (int)(quirks & DETEXHIP_QUIRKS_REFERENCE); }
 extern "C" uint32_t detexhipGetQuirks(void) { (void)current_spec_flags(); return (uint32_t)thread_settings().quirks; }
 
-extern "C" int detexhipSetReadAhead(int on) { const int before = current_read_ahead() ? 1 : 0; thread_settings().read_ahead = on ? 1 : 0; return before; }
+extern "C" int detexhipSetReadAhead(int mode) { const int before = current_read_ahead(); thread_settings().read_ahead = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return before; }
 
 extern "C" void detexhipSetKernelVariant(int variant) { thread_settings().variant = (variant >= 0 && variant <= max_variant()) ? variant : 0; }
 extern "C" int detexhipGetKernelVariant(void) { return current_variant(); }

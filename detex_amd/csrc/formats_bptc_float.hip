@@ -11,11 +11,12 @@ namespace detexhip {
 
 // (resident workgroups per CU: BC6H gains 11 % on coherent content at five -- its fixture tiled, which is what encoder-made textures
 // look like -- at the price of 2.6 % on uniform-random blocks, where the kernel sits at the board's power cap and needs every wave;
-// signed BC6H has no fixture to show a gain and keeps all of them.  Block-major: four.)
+// signed BC6H has no fixture to show a gain and keeps all of them.  Block-major: four until round 6, uncapped since -- 99.9 -> 93.7 us with the
+// blocks coming out of HBM and 85.9 -> 83.5 on a repeated input (profiles/r06/rotating_wg_sweep_tiled.txt).)
 // (a function-local table: a namespace-scope const object would also be emitted into the device code object, where the launchers do not exist)
 const FormatEntry *formats_bptc_float() {
 	static const FormatEntry rows[2] = {
-		FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 4), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
+		FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 0), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
 	};
 	return rows;
 }

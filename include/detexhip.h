@@ -242,12 +242,18 @@ enum { DETEXHIP_QUIRK_BC7_MODE6_PBIT = 1, DETEXHIP_QUIRK_BC6H_MODE12_BIT63 = 2, 
 DETEXHIP_API void detexhipSetQuirks(uint32_t quirks);
 DETEXHIP_API uint32_t detexhipGetQuirks(void);
 
-/* Textures whose compressed blocks exceed the GPU's 256 MiB memory-side cache (32768 x 32768 BC1: 512 MiB of blocks) are decoded by
- * detexhipDecompressTextureLinearDevice in bands of block rows, each band's blocks (at most 128 MiB) read into that cache by a read-only
- * pass before the band is decoded -- several launches on the caller's stream instead of one; same pixels, same status word.  HBM then sees
- * a read phase and a write phase per band instead of reads scattered through the write stream.  On by default; 0 = always one launch
- * (DETEXHIP_READ_AHEAD=0 in the environment does the same).  Per calling thread.  Returns the previous setting. */
-DETEXHIP_API int detexhipSetReadAhead(int on);
+/* Read-ahead of the compressed blocks (detexhipDecompressTextureLinearDevice and everything built on it).  Blocks that come out of HBM in
+ * the middle of the pixel write stream cost more than their bytes (HBM serves a read scattered among writes about three times slower);
+ * blocks that sit in the GPU's 256 MiB memory-side cache (Infinity Cache) do not.  With read-ahead the texture is decoded in bands of block
+ * rows, each band's blocks (at most 128 MiB) first read into that cache by a read-only pass -- several launches on the caller's stream
+ * instead of one; same pixels, same status word.
+ *   1 (default)  textures whose blocks alone exceed that cache and therefore cannot be resident in it (32768 x 32768 BC1: 512 MiB of
+ *                blocks: 0.74 -> 0.82 of the HBM peak, BC6H 0.71 -> 0.80)
+ *   2            every texture with at least 1 MiB of blocks: for a caller who knows the blocks are NOT in the cache (freshly produced
+ *                input, a stream of different textures); costs ~14 % where they are (a texture decoded again and again)
+ *   0            never: always one launch
+ * DETEXHIP_READ_AHEAD in the environment sets the initial mode.  Per calling thread.  Returns the previous mode. */
+DETEXHIP_API int detexhipSetReadAhead(int mode);
 
 /* Kernel-variant selection for A/B measurements (profiles/AB_RECORD.md).  The product library has ONE kernel per
  * format and layout (variant 0); the rejected alternatives exist only in the measurement build (make lib-ab:

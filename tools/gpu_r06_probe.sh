@@ -1,10 +1,11 @@
 set -u
 mkdir -p gpurun_out/r06
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06/bench_a.json 2> gpurun_out/r06/bench_a.err; tail -3 gpurun_out/r06/bench_a.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/r06/bench_b.json 2> gpurun_out/r06/bench_b.err; tail -3 gpurun_out/r06/bench_b.err
 python - <<'PY'
 import json
-r = json.load(open("gpurun_out/r06/bench_a.json"))
-print(json.dumps({k: r[k] for k in ("value", "ms_per_step", "roofline")})[:600])
-print(json.dumps(r.get("strong_image_32768"), indent=1)); print(json.dumps(r.get("bc6h_32768_whole"), indent=1))
-print(json.dumps(r["host_tier_small"].get("oneshot_compiled_c_client"), indent=1)); print(json.dumps(r["host_tier_small"].get("oneshot_reference_compiled_c_client")))
+r = json.load(open("gpurun_out/r06/bench_b.json"))
+print(r["value"], r["roofline"]["frac"], r["roofline"]["launch_us"])
+print(json.dumps({k: v for k, v in r["roofline"]["blocks_from_hbm"].items() if k != "note"}))
+for k, v in r["per_format"]["formats"].items():
+    if "blocks_from_hbm" in v: print(k, v["launch_us"], v["frac"], json.dumps(v["blocks_from_hbm"]))
 PY
