@@ -42,6 +42,14 @@ int epilogue_for(uint32_t texture_format, uint32_t pixel_format) {
 	return -1;
 }
 bool pixel_format_accepted(uint32_t texture_format, uint32_t pixel_format) { return epilogue_for(texture_format, pixel_format) >= 0; }
+// a pixel format with the pixel size the epilogue `epi` writes for this texture format (for address arithmetic: bytes per block = 16 x its size)
+static uint32_t epilogue_target_of(uint32_t texture_format, int epi) {
+	switch (epi) {
+	case kEpiPackRGB8: case kEpiToRGB8: return kPixelRGB8;
+	case kEpiToRGBX8: case kEpiToBGRX8: return DETEX_PIXEL_FORMAT_RGBX8;
+	default: return texture_format & DETEX_TEXTURE_FORMAT_PIXEL_FORMAT_MASK;		// native size (kEpiNone and the channel swaps)
+	}
+}
 
 int prepared_epilogue(uint32_t texture_format, uint32_t pixel_format, hipStream_t stream) {
 	const int epi = epilogue_for(texture_format, pixel_format);
@@ -218,6 +226,24 @@ static int blocks_device(const char *who, uint32_t texture_format, const void *d
 	}
 	// the reference's flags occupy bits 0-2 (detex.h:397-411); the spec switches ride in bits 30-31
 	BatchArgs a{ d_blocks, d_pixels, n_blocks, mode_mask, (flags & 0x3FFFFFFFu) | current_spec_flags(), d_ok, d_status, static_cast<hipStream_t>(stream), checked, epi, f->resident_blocks };
+	// the same read-ahead as the linear layout (linear_device_with): a block-major stream is contiguous on both sides, so a band is simply a
+	// run of blocks (whole 256-block tiles) and the pixels behind the run before it
+	const size_t bs = detexGetCompressedBlockSize(texture_format), total = n_blocks * bs;
+	const int read_ahead = current_read_ahead();
+	if ((read_ahead == 1 && total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && total >= ((size_t)1 << 20))) {
+		const size_t band_blocks = (Tune::kReadAheadBandBytes / bs) & ~(size_t)255, out_per_block = 16u * (size_t)detexGetPixelSize(epilogue_target_of(texture_format, epi));
+		for (size_t b0 = 0; b0 < n_blocks; b0 += band_blocks) {
+			BatchArgs band = a;
+			band.n = b0 + band_blocks < n_blocks ? band_blocks : n_blocks - b0;
+			band.blocks = static_cast<const uint8_t *>(d_blocks) + b0 * bs;
+			band.pixels = static_cast<uint8_t *>(d_pixels) + b0 * out_per_block;
+			band.ok = d_ok ? d_ok + b0 : nullptr;
+			hipError_t e = launch_read_ahead(band.blocks, band.n * bs, band.stream);
+			if (e == hipSuccess) e = f->blocks(band);
+			if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
+		}
+		return 0;
+	}
 	hipError_t e = f->blocks(a);
 	if (e != hipSuccess) { detexSetErrorMessage("libdetexhip: kernel launch failed: %s", hipGetErrorString(e)); return 1; }
 	return 0;

@@ -635,6 +635,43 @@ def test_whole_32768_image_in_one_call_banded_read_ahead(name, torch_cuda, golde
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("layout", ["linear", "tiled"])
+def test_read_ahead_mode_2_bands_and_matches_one_launch(layout, torch_cuda, oracle):
+    """detexhipSetReadAhead(2): every texture with >= 1 MiB of blocks goes in bands of <= 128 MiB of blocks behind a read-only pass -- here
+    BPTC 16384^2 (256 MiB of blocks: two bands) and a 2 MiB one (one band), both layouts: identical bytes and status word to the single
+    launch of mode 0, and the first block rows equal to the oracle's"""
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME["BPTC"]
+    for side in (16384, 1448 // 4 * 4):
+        wb = hb = side // 4
+        data = ol.stream_u(fmt, wb * hb, seed=0x2EAD + side)
+        d = _dev(torch, data)
+        outs, stats = [], []
+        try:
+            for mode in (0, 2):
+                binding.set_read_ahead(mode)
+                status = torch.zeros(1, dtype=torch.int32, device="cuda")
+                if layout == "tiled":
+                    out = binding.decompress_tiled_device(fmt, d, wb, hb, status=status)
+                else:
+                    out = binding.decompress_linear_device(fmt, d, side, side, status=status)
+                torch.cuda.synchronize()
+                outs.append(out); stats.append(int(status.item()))
+        finally:
+            binding.set_read_ahead(1)
+        assert torch.equal(outs[0], outs[1]) and stats[0] == stats[1], (layout, side)
+        rows = 4
+        sub = data[:rows * wb * fmt.block_bytes]
+        if layout == "tiled":
+            _, want = oracle.tiled_to(fmt, sub, wb, rows, F.native_pixel_format(fmt))
+        else:
+            _, want = oracle.linear(fmt, sub, side, rows * 4)
+        assert np.array_equal(outs[1][:want.size].cpu().numpy(), want.reshape(-1)), (layout, side)
+        del d, outs
+        torch.cuda.empty_cache()
+
+
 def test_empty_inputs(hiplib, torch_cuda):
     """empty textures / zero blocks: the reference's loops simply do not run (texture.c:111-144 -> true, nothing
     written); no launch with an empty grid, no error text"""

@@ -59,6 +59,20 @@ print(sys.argv[2], "stream U, per wave:", {k: round(v / w, 1) for k, v in m.item
 PY
   rm -rf $OUT/sq_$FMT
 done | tee $OUT/sq_per_wave.txt
+echo "== round 6: the large-footprint cliff (sweep, mock, mix, counters), blocks out of HBM (rotating inputs), block-major BC7 against linear, the one-shot client"
+bash tools/gpu_big_footprint.sh $OUT/footprint > $OUT/footprint.log 2>&1; tail -2 $OUT/footprint/sweep_bc1.jsonl | cut -c1-300
+rm -f $OUT/footprint/*.err
+python tools/gpu_rotating.py detex_amd/lib/libdetexhip.so BC1,BC1A,BC2,BC3,RGTC2,SIGNED_RGTC2,BPTC_FLOAT,BPTC_SIGNED_FLOAT,BPTC,ETC1,ETC2,ETC2_PUNCHTHROUGH,ETC2_EAC,EAC_RG11,EAC_SIGNED_RG11 8192 1,2 2>/dev/null > $OUT/rotating_inputs_8192.jsonl
+python tools/gpu_rotating.py detex_amd/lib/libdetexhip.so BC1,BC3,BPTC,ETC2,ETC2_EAC,BPTC_FLOAT 8192 1,2 tiled 2>/dev/null > $OUT/rotating_inputs_8192_tiled.jsonl; wc -l $OUT/rotating_inputs_8192*.jsonl
+bash tools/gpu_bc7_tiled_account.sh $OUT/bc7_tiled > $OUT/bc7_tiled.log 2>&1; rm -f $OUT/bc7_tiled/*.log; cat $OUT/bc7_tiled/times.jsonl | cut -c1-160
+V="BC1 BC1A BC2 BC3 RGTC1 RGTC2 SIGNED_RGTC1 SIGNED_RGTC2 BPTC BPTC_FLOAT ETC1 ETC2 ETC2_PUNCHTHROUGH ETC2_EAC EAC_R11 EAC_RG11 EAC_SIGNED_R11"; F=""; for v in $V; do F="$F $ROOT/tests/golden/test-texture-$v.ktx"; done
+mkdir -p $OUT/oneshot
+for i in 1 2 3 4 5 6 7 8 9 10; do tests/c_client/detex_client --oneshot-breakdown $F; done > $OUT/oneshot/oneshot_breakdown.txt 2>&1
+[ -x tests/c_client/detex_client_reflib ] && for i in 1 2 3; do tests/c_client/detex_client_reflib --oneshot $F; done >> $OUT/oneshot/oneshot_breakdown.txt 2>&1
+(cd /tmp && timeout 300 rocprofv3 --hip-trace --kernel-trace --stats -d $ROOT/$OUT/oneshot/trace -o t --output-format csv -- $ROOT/tests/c_client/detex_client --oneshot $F > $ROOT/$OUT/oneshot/trace.log 2>&1)
+f=$(find $OUT/oneshot/trace -name "*hip_api_stats.csv" | head -1); [ -n "$f" ] && head -12 $f | tee $OUT/oneshot/oneshot_hip_api_stats.csv | head -6
+f=$(find $OUT/oneshot/trace -name "*hip_api_trace.csv" | head -1); [ -n "$f" ] && grep -v "__hipRegister" $f > $OUT/oneshot/oneshot_hip_api_trace.csv
+rm -rf $OUT/oneshot/trace $OUT/oneshot/trace.log
 echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
 if ! skip fuzz; then echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 50000 2>&1 | tail -1 | tee $OUT/fuzz.log; fi
 rm -rf $OUT/pmc_*_*_*_* $OUT/pmc_*_*_* 2>/dev/null
