@@ -135,6 +135,25 @@ template <int POLICY, int DWORDS, class V, class P> DH void store_with_policy(V 
 	}
 }
 
+// A block load with a second, never-used load of the same width issued right behind it (a read-ahead: `ahead` is only wanted in the
+// caches).  Loads return in order, so the wait is for all but the last one: the block is there, the read-ahead still travelling.  The
+// compiler does not know about that outstanding load: the caller keeps `sink` alive to the end of the kernel (keep_alive) so that its
+// registers are not handed to anything else before the data lands; s_endpgm waits for it.
+template <class Word> struct ReadAheadSink;
+template <> struct ReadAheadSink<uint4> { u32x4 v; };
+template <> struct ReadAheadSink<uint2> { u32x2 v; };
+DH void load_with_read_ahead(const uint4 *block, const uint4 *ahead, uint4 &blk, ReadAheadSink<uint4> &sink) {
+	u32x4 b;
+	asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(1)" : "=&v"(b), "=&v"(sink.v) : "v"(block), "v"(ahead) : "memory");
+	blk = uint4{ b.x, b.y, b.z, b.w };
+}
+DH void load_with_read_ahead(const uint2 *block, const uint2 *ahead, uint2 &blk, ReadAheadSink<uint2> &sink) {
+	u32x2 b;
+	asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off\n\ts_waitcnt vmcnt(1)" : "=&v"(b), "=&v"(sink.v) : "v"(block), "v"(ahead) : "memory");
+	blk = uint2{ b.x, b.y };
+}
+template <class Word> DH void keep_alive(const ReadAheadSink<Word> &s) { asm volatile("" :: "v"(s.v)); }
+
 // Four 16-byte loads that go to memory whatever the caches hold (sc0 sc1: system scope), issued back to back and waited for once:
 // the resident kernel's poll of its request line in pinned host memory (kernels_resident.h) -- one round trip across the link.
 DH void load_system_4x16(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {

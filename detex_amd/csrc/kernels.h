@@ -408,8 +408,16 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	// HBM round trip (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 in the same run).  The load is unconditional, with
 	// the index clamped into the stream: a load under a branch makes the compiler wait for it at the end of the branch.
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	Word blk = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
+	Word blk;
+	ReadAheadSink<Word> ahead;
+	if constexpr (Tune::kPrefetchTiles > 0) {	// MEASUREMENT BUILDS ONLY (Tune::kPrefetchTiles): the blocks of a later tile requested too, and dropped
+		const uint32_t j = i + (uint32_t)Tune::kPrefetchTiles * 256u;
+		load_with_read_ahead(reinterpret_cast<const Word *>(blocks) + (i < n_blocks ? i : n_blocks - 1u), reinterpret_cast<const Word *>(blocks) + (j < n_blocks ? j : n_blocks - 1u), blk, ahead);
+	} else {
+		blk = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
+	}
 	pin_block(blk);
+	struct KeepAhead { const ReadAheadSink<Word> &w; DH ~KeepAhead() { if constexpr (Tune::kPrefetchTiles > 0) keep_alive(w); } } keep_ahead{ ahead };
 	if constexpr (ROW == 8 && NT) {
 		// 64-bit pixels: rows leave through the per-wave LDS transpose; lanes past the end stay for the exchange
 		// (The branch around the decode costs ~30 v_mov: the compiler initialises the result registers for the lanes that skip it.

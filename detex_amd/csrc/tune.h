@@ -38,6 +38,9 @@ struct ProductTune {
 	// HBM sees a read phase and a write phase instead of reads scattered through the write stream (device_tier.cpp: linear_device_with;
 	// DESIGN.md section 4, "the large-footprint cliff")
 	static constexpr unsigned long kReadAheadBandBytes = 128ul << 20;
+	// decode_linear: every wave also requests the blocks of the tile this many tiles further on (a multiple of eight: the same XCD's L2) and
+	// never uses them -- a read-ahead inside the launch for blocks that come out of HBM (0 = none; measurement: profiles/AB_RECORD.md round 6)
+	static constexpr int kPrefetchTiles = 0;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store
