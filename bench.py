@@ -15,9 +15,12 @@ prints ONE JSON line on rank 0.
             of configs[1..4] at 8192^2, streams U/M/C, plus the weakest kernels -- signed BC6H,
             block-major BC7, RGTC1 -- each timed at steady state), `beyond_mall`,
             `per_format.beyond_cache_16384` (the six headline formats, and the five formats whose 8192^2 footprint fits the Infinity Cache, at 16384^2), `cold` (first launch after idle, mean of the first
-            twenty, the contract's W + K started cold), `strong_image_32768` (this GPU alone on the N>1 workload), `host_tier`,
-            `host_tier_small` (per-call latency of small textures / one block through the host API,
-            beside the reference on one host thread), `cpu_baseline`.
+            twenty, the contract's W + K started cold), `roofline.blocks_from_hbm` / `per_format.formats.*.blocks_from_hbm` (the same launch
+            over R different inputs in turn: the timed loop re-reads its ONE input's blocks from the 256 MiB Infinity Cache, this is every byte
+            through HBM), `strong_image_32768` / `bc6h_32768_whole` (this GPU alone on the N>1 workloads: the WHOLE 32768^2 image through one call of
+            the device entry, with the one-launch figure and a quarter-image band beside it), `host_tier`,
+            `host_tier_small` (per-call latency of small textures / one block through the host API, beside the reference on one host thread;
+            `oneshot_*`: a fresh process decoding the 17 bundled fixtures once), `cpu_baseline`.
   N > 1     BASELINE north_star: ONE 32768 x 32768 BC1 image sharded by block rows over the ranks
             (contiguous input and output ranges per rank, NO data-path collective)
             -> "scaling": "strong", value = 32768^2 * K / max-over-ranks(wall time of K steps).
@@ -46,6 +49,11 @@ prints ONE JSON line on rank 0.
             the Infinity Cache).
   cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or our C restatement
             (kind "port") decoding the same stream on the host cores; rank 0, N == 1 only.
+
+Layout of this file: cpu_baseline / Telemetry / live_pmc_traffic / roofline_row (no GPU needed: tests/test_bench_helpers.py), Job and
+RotatingInputs (device-resident input and output of one decode call), class Bench -- __init__: process group and workload geometry; helpers
+(barrier, timed, steady_state_us, ...); one method per part of the line (measure_headline, multi_gpu_extras, headline_result, add_*); run() --
+and main(): arguments, stdout hand-over, late imports.
 """
 import argparse
 import ctypes
@@ -244,94 +252,132 @@ def roofline_row(alg_bytes, write_bytes, pixels, launch_us):
     return row
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--format", default="BC1")
-    ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
-    ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
-    ap.add_argument("--strong-image", type=int, default=None,
-                    help="strong scaling: ONE S x S image sharded by block rows over the ranks; default 32768 (BASELINE "
-                         "north_star) when N > 1, off when N == 1")
-    ap.add_argument("--weak", action="store_true", help="N > 1: one --size^2 image per rank as the headline (round-1 behaviour)")
-    ap.add_argument("--variant", type=int, default=0, help="A/B kernel variant (needs DETEXHIP_LIB=<make lib-ab build>)")
-    ap.add_argument("--stream", default="U", choices=["U", "M", "C"])
-    ap.add_argument("--layout", default="linear", choices=["linear", "tiled"],
-                    help="linear = detexDecompressTextureLinear (headline); tiled = detexDecompressTextureTiled (block-major output)")
-    ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-settle", action="store_true", help="start the contract's W + K launches cold (no settling launches before them)")
-    ap.add_argument("--no-extras", action="store_true", help="skip per_format / strong_image_32768 / weak / gather extras")
-    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is timed by default when N > 1)")
-    ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
-    args = ap.parse_args()
+# torch, torch.distributed and the package are imported in main(), after stdout has been handed to stderr (gloo and RCCL print there)
+torch = dist = binding = F = sharding = ol = streams = None
 
-    # The contract is ONE JSON line on stdout.  Libraries print there too (gloo announces its connections, RCCL its version banner when
-    # NCCL_DEBUG is set, rocprofv3 its summary): from here on file descriptor 1 is stderr's, and the line at the end goes to the saved one.
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-    from detex_amd import binding, formats as F, sharding
-    import oracle_lib as ol
-    import streams
+class Job:
+    """device-resident input/output of one decode call"""
+    def __init__(self, fmt, W, H, data, layout, pf, tpx):
+        self.fmt, self.W, self.H, self.data, self.layout = fmt, W, H, data, layout
+        self.pf, self.tpx = pf, tpx
+        self.d_blocks = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        self.d_out = torch.empty(W * H * self.tpx, dtype=torch.uint8, device="cuda")
+        self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.blocks = (W // 4) * (H // 4)
+        self.alg_bytes = self.blocks * (fmt.block_bytes + 16 * self.tpx)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        log("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus))
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        log("bench.py: no HIP device; the decode path has no CPU fallback")
-        sys.exit(3)
-    # DETEX_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (all ranks share
-    # cuda:0; a plumbing test, not a measurement).  The driver's runs use RCCL ("nccl").
-    backend = os.environ.get("DETEX_BENCH_BACKEND", "nccl")
-    # (a launcher that shows every rank only its own GPU leaves one visible device per process: device 0 is then the rank's)
-    ndev = torch.cuda.device_count()
-    device_index = local_rank if (backend == "nccl" and local_rank < ndev) else local_rank % ndev
-    torch.cuda.set_device(device_index)
-    rccl_ranks = 1
-    # DETEX_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, rank census, barriers, band digests, both gathers) at ANY world size
-    # -- with WORLD_SIZE 1 and the nccl backend this is the pre-flight of the RCCL path on a one-GPU box (tests/test_gpu_rccl_preflight.py)
-    multi = world > 1 or os.environ.get("DETEX_BENCH_FORCE_DIST") == "1"
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        # The census comes FIRST and travels over gloo (CPU tensors of a mixed-backend group): which GPU each rank sits on, by PCI address.
-        # Two ranks on one GPU -- torchrun --nproc-per-node N on a box with fewer GPUs -- would make RCCL abort inside its communicator
-        # set-up ("Duplicate GPU detected"); found here, before any RCCL call, the run ends with a message and exit code 5 instead.
-        dist.init_process_group("cpu:gloo,cuda:nccl" if backend == "nccl" else backend, rank=rank, world_size=world)
-        prop = torch.cuda.get_device_properties(device_index)
-        mine = torch.tensor([device_index, getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1), getattr(prop, "pci_domain_id", -1)], dtype=torch.int64)
-        seen = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(seen, mine)
-        places = [tuple(int(v) for v in t.tolist()) for t in seen]
-        # distinct GPUs: by PCI address where the runtime reports one, else by device index (which then must not have been folded)
-        by_pci = all(p[1] >= 0 for p in places)
-        distinct = len({p[1:] for p in places}) == world if by_pci else (len({p[0] for p in places}) == world and world <= ndev)
-        if backend == "nccl" and (args.gpus != world or not distinct):
-            log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, visible devices %d, (device, pci bus, pci device, pci domain) per rank %s"
-                % (rank, args.gpus, world, torch.cuda.device_count(), places))
-            dist.destroy_process_group()
-            sys.exit(5)
-        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(ones)                  # (the first CUDA collective: RCCL builds its communicator here)
-        rccl_ranks = int(ones.item())          # ranks the collective library actually reached
-        if backend == "nccl" and rccl_ranks != world:
-            log("bench.py: rank %d: the all_reduce reached %d of %d ranks" % (rank, rccl_ranks, world))
-            dist.destroy_process_group()
-            sys.exit(5)
-    binding.load()
-    binding.set_kernel_variant(args.variant)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    def step(self):
+        if self.layout == "tiled":
+            binding.decompress_tiled_device(self.fmt, self.d_blocks, self.W // 4, self.H // 4, out=self.d_out, status=self.status, pixel_format=self.pf)
+        else:
+            binding.decompress_linear_device(self.fmt, self.d_blocks, self.W, self.H, out=self.d_out, status=self.status, pixel_format=self.pf)
 
-    def barrier():
+    def verify(self, rows=64):
+        """bit-exactness of what was just timed against the CPU checker on a bounded sample (first `rows` block rows)"""
+        rows = min(rows, self.H // 4)
+        orc = ol.Oracle()
+        sub = self.data[:rows * (self.W // 4) * self.fmt.block_bytes]
+        if self.layout == "tiled":
+            _, want = orc.tiled_to(self.fmt, sub, self.W // 4, rows, self.pf)
+        else:
+            _, want = orc.linear_to(self.fmt, sub, self.W, rows * 4, self.pf)
+        got = self.d_out[:want.size].cpu().numpy()
+        return rows * 4 if np.array_equal(got, want) else 0
+
+
+class RotatingInputs:
+    """the same decode over R DIFFERENT input buffers in turn (R x blocks > 2.5 x the 256 MiB Infinity Cache), one output image: every
+    launch's blocks come out of HBM -- the regime of a stream of different textures.  (A loop over ONE input re-reads its blocks from
+    that memory-side cache: HBM then sees the writes only, and `frac` counts bytes HBM never delivered -- DESIGN.md section 4.)"""
+    def __init__(self, job):
+        self.job = job
+        n = int(job.d_blocks.numel())
+        self.inputs = [job.d_blocks] + [torch.roll(job.d_blocks, 4096 * k) for k in range(1, max(3, -(-(640 << 20) // n)))]
+        self.k = 0
+        self.blocks, self.alg_bytes, self.tpx, self.W, self.H = job.blocks, job.alg_bytes, job.tpx, job.W, job.H
+
+    def step(self):
+        j = self.job
+        self.k = (self.k + 1) % len(self.inputs)
+        binding.decompress_linear_device(j.fmt, self.inputs[self.k], j.W, j.H, out=j.d_out, status=j.status, pixel_format=j.pf)
+
+
+class Bench:
+    """One run: the process-group set-up and the workload geometry (__init__), the measurement helpers, and one method per part of the JSON line
+    (run() at the end calls them in order)."""
+
+    def __init__(self, args):
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != world and world == 1 and args.gpus > 1:
+            log("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus))
+            sys.exit(2)
+        if not torch.cuda.is_available():
+            log("bench.py: no HIP device; the decode path has no CPU fallback")
+            sys.exit(3)
+        # DETEX_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (all ranks share
+        # cuda:0; a plumbing test, not a measurement).  The driver's runs use RCCL ("nccl").
+        backend = os.environ.get("DETEX_BENCH_BACKEND", "nccl")
+        # (a launcher that shows every rank only its own GPU leaves one visible device per process: device 0 is then the rank's)
+        ndev = torch.cuda.device_count()
+        device_index = local_rank if (backend == "nccl" and local_rank < ndev) else local_rank % ndev
+        torch.cuda.set_device(device_index)
+        rccl_ranks = 1
+        # DETEX_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, rank census, barriers, band digests, both gathers) at ANY world size
+        # -- with WORLD_SIZE 1 and the nccl backend this is the pre-flight of the RCCL path on a one-GPU box (tests/test_gpu_rccl_preflight.py)
+        multi = world > 1 or os.environ.get("DETEX_BENCH_FORCE_DIST") == "1"
+        if multi:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            # The census comes FIRST and travels over gloo (CPU tensors of a mixed-backend group): which GPU each rank sits on, by PCI address.
+            # Two ranks on one GPU -- torchrun --nproc-per-node N on a box with fewer GPUs -- would make RCCL abort inside its communicator
+            # set-up ("Duplicate GPU detected"); found here, before any RCCL call, the run ends with a message and exit code 5 instead.
+            dist.init_process_group("cpu:gloo,cuda:nccl" if backend == "nccl" else backend, rank=rank, world_size=world)
+            prop = torch.cuda.get_device_properties(device_index)
+            mine = torch.tensor([device_index, getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1), getattr(prop, "pci_domain_id", -1)], dtype=torch.int64)
+            seen = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(seen, mine)
+            places = [tuple(int(v) for v in t.tolist()) for t in seen]
+            # distinct GPUs: by PCI address where the runtime reports one, else by device index (which then must not have been folded)
+            by_pci = all(p[1] >= 0 for p in places)
+            distinct = len({p[1:] for p in places}) == world if by_pci else (len({p[0] for p in places}) == world and world <= ndev)
+            if backend == "nccl" and (args.gpus != world or not distinct):
+                log("bench.py: rank %d: NOT one rank per GPU: --gpus %d, WORLD_SIZE %d, visible devices %d, (device, pci bus, pci device, pci domain) per rank %s"
+                    % (rank, args.gpus, world, torch.cuda.device_count(), places))
+                dist.destroy_process_group()
+                sys.exit(5)
+            ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(ones)                  # (the first CUDA collective: RCCL builds its communicator here)
+            rccl_ranks = int(ones.item())          # ranks the collective library actually reached
+            if backend == "nccl" and rccl_ranks != world:
+                log("bench.py: rank %d: the all_reduce reached %d of %d ranks" % (rank, rccl_ranks, world))
+                dist.destroy_process_group()
+                sys.exit(5)
+        binding.load()
+        binding.set_kernel_variant(args.variant)
+        coll_dev = "cuda" if backend == "nccl" else "cpu"
+        telemetry = Telemetry(torch, device_index)
+        fmt = F.BY_NAME[args.format]
+        # (plumbing runs over gloo move CUDA tensors through the host at ~0.03 GB/s point-to-point: they get small images)
+        big = 32768 if backend == "nccl" else 2048
+        strong = args.strong_image if args.strong_image is not None else (0 if (not multi or args.weak) else big)
+        W = H = args.size
+        if args.band_height:
+            H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
+        if strong:
+            shard = sharding.shard_of(rank, world, fmt, strong, strong)
+            W, H = strong, (shard.row1 - shard.row0) * 4
+        if not strong:
+            shard = None
+        self.args, self.world, self.rank, self.local_rank, self.backend, self.device_index, self.multi, self.rccl_ranks = args, world, rank, local_rank, backend, device_index, multi, rccl_ranks
+        self.coll_dev, self.telemetry, self.fmt, self.big, self.strong, self.W, self.H, self.shard = coll_dev, telemetry, fmt, big, strong, W, H, shard
+        self.extras = {}
+
+    # ---- helpers ------------------------------------------------------------------------------------------------------------------------------
+    def barrier(self):
+        backend, device_index, multi = self.backend, self.device_index, self.multi
         torch.cuda.synchronize()
         if multi:
             if backend == "nccl":
@@ -340,72 +386,30 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-    TARGETS = {"BGRA8": F.PIXEL_FORMAT_BGRA8, "BGRX8": F.PIXEL_FORMAT_BGRX8, "RGB8": F.PIXEL_FORMAT_RGB8,
-               "FLOAT_BGRX16": F.PIXEL_FORMAT_FLOAT_BGRX16, "RGBA8": F.PIXEL_FORMAT_RGBA8}
-
-    def target_of(fmt, target=None):
+    def target_of(self, fmt, target=None):
+        TARGETS = {"BGRA8": F.PIXEL_FORMAT_BGRA8, "BGRX8": F.PIXEL_FORMAT_BGRX8, "RGB8": F.PIXEL_FORMAT_RGB8,
+                   "FLOAT_BGRX16": F.PIXEL_FORMAT_FLOAT_BGRX16, "RGBA8": F.PIXEL_FORMAT_RGBA8}
         pf = TARGETS[target] if target else F.native_pixel_format(fmt)
         return pf, 1 + ((pf & 0xF00) >> 8)
 
-    def stream_seed(fmt, shift):
+    def stream_seed(self, fmt, shift):
         return ol.STREAM_SEED_BASE + ol.STREAM_SEED_K.get(fmt.name, 16 + fmt.index) + (shift << 8)
 
-    def make_input(fmt, wb, hb, kind, seed_shift=0):
-        return streams.make_stream(kind, fmt, wb, hb, seed=stream_seed(fmt, seed_shift))
+    def make_input(self, fmt, wb, hb, kind, seed_shift=0):
+        return streams.make_stream(kind, fmt, wb, hb, seed=self.stream_seed(fmt, seed_shift))
 
-    class Job:
-        """device-resident input/output of one decode call"""
-        def __init__(self, fmt, W, H, data, layout="linear", target=None):
-            self.fmt, self.W, self.H, self.data, self.layout = fmt, W, H, data, layout
-            self.pf, self.tpx = target_of(fmt, target)
-            self.d_blocks = torch.from_numpy(np.ascontiguousarray(data)).cuda()
-            self.d_out = torch.empty(W * H * self.tpx, dtype=torch.uint8, device="cuda")
-            self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
-            self.blocks = (W // 4) * (H // 4)
-            self.alg_bytes = self.blocks * (fmt.block_bytes + 16 * self.tpx)
+    def new_job(self, fmt, W, H, data, layout="linear", target=None):
+        pf, tpx = self.target_of(fmt, target)
+        return Job(fmt, W, H, data, layout, pf, tpx)
 
-        def step(self):
-            if self.layout == "tiled":
-                binding.decompress_tiled_device(self.fmt, self.d_blocks, self.W // 4, self.H // 4, out=self.d_out, status=self.status, pixel_format=self.pf)
-            else:
-                binding.decompress_linear_device(self.fmt, self.d_blocks, self.W, self.H, out=self.d_out, status=self.status, pixel_format=self.pf)
-
-        def verify(self, rows=64):
-            """bit-exactness of what was just timed against the CPU checker on a bounded sample (first `rows` block rows)"""
-            rows = min(rows, self.H // 4)
-            orc = ol.Oracle()
-            sub = self.data[:rows * (self.W // 4) * self.fmt.block_bytes]
-            if self.layout == "tiled":
-                _, want = orc.tiled_to(self.fmt, sub, self.W // 4, rows, self.pf)
-            else:
-                _, want = orc.linear_to(self.fmt, sub, self.W, rows * 4, self.pf)
-            got = self.d_out[:want.size].cpu().numpy()
-            return rows * 4 if np.array_equal(got, want) else 0
-
-    class RotatingInputs:
-        """the same decode over R DIFFERENT input buffers in turn (R x blocks > 2.5 x the 256 MiB Infinity Cache), one output image: every
-        launch's blocks come out of HBM -- the regime of a stream of different textures.  (A loop over ONE input re-reads its blocks from
-        that memory-side cache: HBM then sees the writes only, and `frac` counts bytes HBM never delivered -- DESIGN.md section 4.)"""
-        def __init__(self, job):
-            self.job = job
-            n = int(job.d_blocks.numel())
-            self.inputs = [job.d_blocks] + [torch.roll(job.d_blocks, 4096 * k) for k in range(1, max(3, -(-(640 << 20) // n)))]
-            self.k = 0
-            self.blocks, self.alg_bytes, self.tpx, self.W, self.H = job.blocks, job.alg_bytes, job.tpx, job.W, job.H
-
-        def step(self):
-            j = self.job
-            self.k = (self.k + 1) % len(self.inputs)
-            binding.decompress_linear_device(j.fmt, self.inputs[self.k], j.W, j.H, out=j.d_out, status=j.status, pixel_format=j.pf)
-
-    def blocks_from_hbm_row(job):
+    def blocks_from_hbm_row(self, job):
         """launch time with the blocks coming out of HBM (rotating inputs), as shipped and with the read-ahead pass forced (detexhipSetReadAhead(2))"""
         rot = RotatingInputs(job)
-        us, _ = steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
+        us, _ = self.steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
         row = {"inputs": len(rot.inputs), "launch_us": round(us, 2), "frac": round(job.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
         binding.set_read_ahead(2)
         try:
-            us2, _ = steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
+            us2, _ = self.steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
         finally:
             binding.set_read_ahead(1)
         row["read_ahead_forced_launch_us"] = round(us2, 2)
@@ -414,18 +418,19 @@ def main():
         torch.cuda.empty_cache()
         return row
 
-    def timed(job, steps, warmup):
+    def timed(self, job, steps, warmup):
         """the contract's timed region: W warm-up launches, then exactly K launches between barriers; wall = max over ranks"""
+        multi, coll_dev = self.multi, self.coll_dev
         for _ in range(warmup):
             job.step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
+        self.barrier()
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
             job.step()
         e1.record()
-        barrier()
+        self.barrier()
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
         if multi:
@@ -434,7 +439,7 @@ def main():
             wall, ev_ms = t.tolist()
         return wall, ev_ms / steps
 
-    def steady_state_us(job, window=100, max_windows=16, tol=0.012, min_launches=600, min_ms=40.0):
+    def steady_state_us(self, job, window=100, max_windows=16, tol=0.012, min_launches=600, min_ms=40.0):
         """launch time once the power-management excursion has passed (profiles/AB_RECORD.md, DESIGN.md section 6: 20-40 % slower for roughly the 2nd to
         12th millisecond after idle -- VALU-heavy kernels and, since round 3, every kernel with `sc1 nt` stores -- then a slow approach
         to the settled clock): windows of launches (>= `window` of them and >= 4 ms each) until two consecutive ones agree within
@@ -461,9 +466,8 @@ def main():
             prev = us
         return us, done
 
-    telemetry = Telemetry(torch, device_index)
-
-    def roofline_of(job, launch_us, clocks=True):
+    def roofline_of(self, job, launch_us, clocks=True):
+        telemetry = self.telemetry
         row = roofline_row(job.alg_bytes, job.blocks * 16 * job.tpx, job.W * job.H, launch_us)
         if clocks:                         # shader clock and board power while this kernel runs back to back (0.15 s, hwmon files)
             t = telemetry.during(job.step)
@@ -472,14 +476,14 @@ def main():
                 row.update(t)
         return row
 
-    def pmc_traffic(key):
+    def pmc_traffic(self, key):
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
             return json.load(open(pmc)).get(key)
         except Exception:  # noqa
             return None
 
-    def hbm_reference(job):
+    def hbm_reference(self, job):
         """write-only fill and copy rates of this box, this process (reference points for the roofline fraction)"""
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -504,82 +508,24 @@ def main():
             log("hbm reference legs failed:", e)
             return {}
 
-    fmt = F.BY_NAME[args.format]
-    # (plumbing runs over gloo move CUDA tensors through the host at ~0.03 GB/s point-to-point: they get small images)
-    big = 32768 if backend == "nccl" else 2048
-    strong = args.strong_image if args.strong_image is not None else (0 if (not multi or args.weak) else big)
-    W = H = args.size
-    if args.band_height:
-        H = args.band_height          # e.g. --size 32768 --band-height 4096: one GPU's band of a 32768^2 image over 8 GPUs
-    if strong:
-        shard = sharding.shard_of(rank, world, fmt, strong, strong)
-        W, H = strong, (shard.row1 - shard.row0) * 4
-    def band_stream(f, image_side, sh, kind="U"):
+    def band_stream(self, f, image_side, sh, kind="U"):
         """this rank's band of the image's block stream: splitmix64 is counter-based (word k depends on k only), so the
         band is the slice [row0 * words_per_row, row1 * words_per_row) and a rank materialises nothing else"""
         words_per_row = (image_side // 4) * f.block_bytes // 8
         with np.errstate(over="ignore"):
             k = np.arange(sh.row0 * words_per_row + 1, sh.row1 * words_per_row + 1, dtype=np.uint64)
-            z = np.uint64(stream_seed(f, 0)) + np.uint64(0x9E3779B97F4A7C15) * k
+            z = np.uint64(self.stream_seed(f, 0)) + np.uint64(0x9E3779B97F4A7C15) * k
             z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
             z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
             z = z ^ (z >> np.uint64(31))
         d = z.view(np.uint8)
         return streams.stream_m(f, d) if kind == "M" else d
 
-    if strong and args.stream != "C":
-        data = band_stream(fmt, strong, shard, args.stream)
-    else:
-        data = make_input(fmt, W // 4, H // 4, args.stream, 0 if strong else rank)
-        if data is None:
-            log("bench.py: stream C needs a bundled fixture of", fmt.name)
-            sys.exit(4)
-    job = Job(fmt, W, H, data, args.layout, args.target)
-    # Before the contract's W + K launches: run the kernel until its launch time has settled (the same criterion as the per-format
-    # table).  The first ~250 launches after idle are not representative of a decode stream -- VALU-heavy kernels slow down for
-    # a few hundred launches while the power management reacts, and the `sc1 nt` row stores of round 3 show the same excursion
-    # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ...) -- so a
-    # timed region of 20-200 launches right after start-up would measure the excursion, not the kernel.  --no-settle skips it.
-    cold = {}
-    if not args.no_settle:
-        # what a caller who decodes ONE texture sees: the first launch after idle and the mean of the first twenty (an event per launch),
-        # then -- idle again -- the contract's W + K launches started cold (`value_cold`: the measurement of rounds 1 and 2)
-        job.step(); torch.cuda.synchronize()                                 # (the very first launch also loads the code object: not counted)
-        time.sleep(0.3)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-        evs[0].record()
-        for k in range(20):
-            job.step()
-            evs[k + 1].record()
-        torch.cuda.synchronize()
-        per = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(20)]
-        cold["cold_first_launch_us"] = round(per[0], 2)
-        cold["first_20_mean_us"] = round(sum(per) / 20, 2)
-        time.sleep(0.3)
-        wall_c, launch_ms_c = timed(job, args.steps, args.warmup)
-        image_pixels_c = strong * strong if strong else world * W * H
-        cold["value_cold"] = round(image_pixels_c * args.steps / wall_c / 1e9, 3)
-        cold["ms_per_step_cold"] = round(wall_c / args.steps * 1e3, 5)
-        cold["launch_us_cold"] = round(launch_ms_c * 1e3, 3)
-        cold["note"] = ("started 0.3 s after the previous launch: the first launch, the mean of the first 20 (one HIP event pair each), and the contract's W + K "
-                        "launches without the settling phase that precedes `value`")
-    settle_us, settle_launches = (None, 0) if args.no_settle else steady_state_us(job)
-    wall, launch_ms = timed(job, args.steps, args.warmup)
-    image_pixels = strong * strong if strong else world * W * H
-    gpix = image_pixels * args.steps / wall / 1e9
-    achieved = job.alg_bytes / (launch_ms * 1e-3) / 1e9
-
-    # what every rank just wrote, checked against the CPU oracle on a bounded sample; AND over ranks
-    verified_rows = job.verify(16 if multi else 64)
-    if multi:
-        v = torch.tensor([verified_rows], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN)
-        verified_rows = int(v.item())
-
-    def band_digests_match(f, side, sh, d_out):
+    def band_digests_match(self, f, side, sh, d_out):
         """this rank's whole band against the compiled reference's digests, eighth by eighth (tests/golden/digests_8192.json bands_all:
         the 32768^2 images of BC1 and BPTC_FLOAT in eight bands; a band of world N | 8 ranks is 8 / N consecutive eighths).  None where
         no golden applies."""
+        world = self.world
         import hashlib
         try:
             gold = json.load(open(os.path.join(ROOT, "tests", "golden", "digests_8192.json")))["bands_all"]
@@ -595,70 +541,128 @@ def main():
             ok = ok and hashlib.sha256(piece.cpu().numpy().tobytes()).hexdigest() == g["sha256"]
         return ok
 
-    extras = {}
-    if strong == 32768 and args.stream == "U" and not args.target and args.layout == "linear":
-        mine = band_digests_match(fmt, strong, shard, job.d_out)
-        if mine is not None:
-            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=coll_dev)
-            if multi:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            extras["whole_band_digests_match_reference_all_ranks"] = bool(flag.item())
-            if not mine:
-                log("bench.py: rank %d: WHOLE-BAND DIGEST MISMATCH against the compiled reference" % rank)
-    if multi and not args.no_extras:
-        def time_gathers(f, side, sh, band, reps=2):
-            """the optional whole-image gather, timed separately from the decode (never part of `value`): to ONE rank with grouped
-            point-to-point sends (the root's links to all peers busy at once, nothing lands elsewhere) and to EVERY
-            rank with one all_gather_into_tensor straight into the final image"""
-            out = {}
-            try:
-                ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True)
-                barrier(); t0 = time.perf_counter()
-                for _ in range(reps):
-                    ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True, image=image)
-                barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
-                row = {"op": "sharding.gather_image_to_root (grouped isend / irecv into the root's image)", "ms": round(ms, 3), "bytes_per_rank": int(sh.out_bytes)}
-                if rank == 0:
-                    other = sharding.shard_of(world - 1, world, f, side, side)
-                    row["GBps_into_root"] = round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1)
-                    row["own_band_intact"] = bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes]))
-                    row["peer_band_nonzero"] = bool(image[other.out_offset:other.out_offset + 4096].any().item())
-                out["to_root"] = row
-                del image
-            except Exception as e:  # noqa
-                out["to_root"] = {"error": repr(e)}
-            torch.cuda.empty_cache()
-            try:
-                ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True)
-                barrier(); t0 = time.perf_counter()
-                for _ in range(reps):
-                    ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True, image=image)
-                barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
-                other = sharding.shard_of((rank + 1) % world, world, f, side, side)
-                out["to_all"] = {"op": "sharding.gather_image (all_gather_into_tensor into the final image)", "ms": round(ms, 3), "image_bytes": int(image.numel()),
-                                 "GBps_received_per_rank": round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1),
-                                 "own_band_intact": bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes])),
-                                 "peer_band_nonzero": bool(image[other.out_offset:other.out_offset + 4096].any().item())}
-                del image
-            except Exception as e:  # noqa
-                out["to_all"] = {"error": repr(e)}
-            torch.cuda.empty_cache()
-            return out
+    def time_gathers(self, f, side, sh, band, reps=2):
+        """the optional whole-image gather, timed separately from the decode (never part of `value`): to ONE rank with grouped
+        point-to-point sends (the root's links to all peers busy at once, nothing lands elsewhere) and to EVERY
+        rank with one all_gather_into_tensor straight into the final image"""
+        world, rank = self.world, self.rank
+        out = {}
+        try:
+            ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True)
+            self.barrier(); t0 = time.perf_counter()
+            for _ in range(reps):
+                ok, image = sharding.gather_image_to_root(dist, torch, f, side, side, sh, band, True, image=image)
+            self.barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
+            row = {"op": "sharding.gather_image_to_root (grouped isend / irecv into the root's image)", "ms": round(ms, 3), "bytes_per_rank": int(sh.out_bytes)}
+            if rank == 0:
+                other = sharding.shard_of(world - 1, world, f, side, side)
+                row["GBps_into_root"] = round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1)
+                row["own_band_intact"] = bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes]))
+                row["peer_band_nonzero"] = bool(image[other.out_offset:other.out_offset + 4096].any().item())
+            out["to_root"] = row
+            del image
+        except Exception as e:  # noqa
+            out["to_root"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True)
+            self.barrier(); t0 = time.perf_counter()
+            for _ in range(reps):
+                ok, image = sharding.gather_image(dist, torch, f, side, side, sh, band, True, image=image)
+            self.barrier(); ms = (time.perf_counter() - t0) / reps * 1e3
+            other = sharding.shard_of((rank + 1) % world, world, f, side, side)
+            out["to_all"] = {"op": "sharding.gather_image (all_gather_into_tensor into the final image)", "ms": round(ms, 3), "image_bytes": int(image.numel()),
+                             "GBps_received_per_rank": round((image.numel() - sh.out_bytes) / (ms * 1e-3) / 1e9, 1),
+                             "own_band_intact": bool(torch.equal(image[sh.out_offset:sh.out_offset + sh.out_bytes], band[:sh.out_bytes])),
+                             "peer_band_nonzero": bool(image[other.out_offset:other.out_offset + 4096].any().item())}
+            del image
+        except Exception as e:  # noqa
+            out["to_all"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        return out
 
+    # ---- the parts of the line ----------------------------------------------------------------------------------------------------------------
+    def measure_headline(self):
+        """the contract's part: this rank's input and output, the cold figures, the settling launches, W + K timed launches, verification"""
+        args, world, rank, multi, coll_dev, fmt, strong, W, H, shard, extras = self.args, self.world, self.rank, self.multi, self.coll_dev, self.fmt, self.strong, self.W, self.H, self.shard, self.extras
+        if strong and args.stream != "C":
+            data = self.band_stream(fmt, strong, shard, args.stream)
+        else:
+            data = self.make_input(fmt, W // 4, H // 4, args.stream, 0 if strong else rank)
+            if data is None:
+                log("bench.py: stream C needs a bundled fixture of", fmt.name)
+                sys.exit(4)
+        job = self.new_job(fmt, W, H, data, args.layout, args.target)
+        # Before the contract's W + K launches: run the kernel until its launch time has settled (the same criterion as the per-format
+        # table).  The first ~250 launches after idle are not representative of a decode stream -- VALU-heavy kernels slow down for
+        # a few hundred launches while the power management reacts, and the `sc1 nt` row stores of round 3 show the same excursion
+        # (BC1, 25-launch windows: 41.6 41.2 44.0 48.6 47.9 46.3 44.4 43.1 42.3 41.2 40.9 41.1 ...) -- so a
+        # timed region of 20-200 launches right after start-up would measure the excursion, not the kernel.  --no-settle skips it.
+        cold = {}
+        if not args.no_settle:
+            # what a caller who decodes ONE texture sees: the first launch after idle and the mean of the first twenty (an event per launch),
+            # then -- idle again -- the contract's W + K launches started cold (`value_cold`: the measurement of rounds 1 and 2)
+            job.step(); torch.cuda.synchronize()                                 # (the very first launch also loads the code object: not counted)
+            time.sleep(0.3)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+            evs[0].record()
+            for k in range(20):
+                job.step()
+                evs[k + 1].record()
+            torch.cuda.synchronize()
+            per = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(20)]
+            cold["cold_first_launch_us"] = round(per[0], 2)
+            cold["first_20_mean_us"] = round(sum(per) / 20, 2)
+            time.sleep(0.3)
+            wall_c, launch_ms_c = self.timed(job, args.steps, args.warmup)
+            image_pixels_c = strong * strong if strong else world * W * H
+            cold["value_cold"] = round(image_pixels_c * args.steps / wall_c / 1e9, 3)
+            cold["ms_per_step_cold"] = round(wall_c / args.steps * 1e3, 5)
+            cold["launch_us_cold"] = round(launch_ms_c * 1e3, 3)
+            cold["note"] = ("started 0.3 s after the previous launch: the first launch, the mean of the first 20 (one HIP event pair each), and the contract's W + K "
+                            "launches without the settling phase that precedes `value`")
+        settle_us, settle_launches = (None, 0) if args.no_settle else self.steady_state_us(job)
+        wall, launch_ms = self.timed(job, args.steps, args.warmup)
+        image_pixels = strong * strong if strong else world * W * H
+        gpix = image_pixels * args.steps / wall / 1e9
+        achieved = job.alg_bytes / (launch_ms * 1e-3) / 1e9
+
+        # what every rank just wrote, checked against the CPU oracle on a bounded sample; AND over ranks
+        verified_rows = job.verify(16 if multi else 64)
+        if multi:
+            v = torch.tensor([verified_rows], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            verified_rows = int(v.item())
+
+        if strong == 32768 and args.stream == "U" and not args.target and args.layout == "linear":
+            mine = self.band_digests_match(fmt, strong, shard, job.d_out)
+            if mine is not None:
+                flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=coll_dev)
+                if multi:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                extras["whole_band_digests_match_reference_all_ranks"] = bool(flag.item())
+                if not mine:
+                    log("bench.py: rank %d: WHOLE-BAND DIGEST MISMATCH against the compiled reference" % rank)
+        self.data, self.job, self.cold, self.settle_us, self.settle_launches = data, job, cold, settle_us, settle_launches
+        self.wall, self.launch_ms, self.gpix, self.achieved, self.verified_rows = wall, launch_ms, gpix, achieved, verified_rows
+
+    def multi_gpu_extras(self):
+        """N > 1 only: the optional gathers of the headline image, BASELINE configs[4] (BC6H 32768^2 over the ranks), the weak-scaling line"""
+        args, world, rank, coll_dev, fmt, big, strong, shard, job, wall, extras = self.args, self.world, self.rank, self.coll_dev, self.fmt, self.big, self.strong, self.shard, self.job, self.wall, self.extras
         # (a) the optional whole-image gather of the headline image
         if strong:
-            extras["gather"] = time_gathers(fmt, strong, shard, job.d_out)
+            extras["gather"] = self.time_gathers(fmt, strong, shard, job.d_out)
             extras["gather"]["decode_ms_per_step"] = round(wall / args.steps * 1e3, 4)
         # (a') BASELINE configs[4]: BC6H -> FLOAT_RGBX16 ("FP16 RGBA"), 32768^2 sharded over the ranks, decode-only and gather separately
         if strong and fmt.name != "BPTC_FLOAT":
             try:
                 f6 = F.BY_NAME["BPTC_FLOAT"]
                 sh6 = sharding.shard_of(rank, world, f6, big, big)
-                d6 = band_stream(f6, big, sh6)
-                j6 = Job(f6, big, (sh6.row1 - sh6.row0) * 4, d6)
-                w6, ms6 = timed(j6, args.steps, max(args.warmup, 10))
+                d6 = self.band_stream(f6, big, sh6)
+                j6 = self.new_job(f6, big, (sh6.row1 - sh6.row0) * 4, d6)
+                w6, ms6 = self.timed(j6, args.steps, max(args.warmup, 10))
                 v6 = j6.verify(16)
-                digest = band_digests_match(f6, big, sh6, j6.d_out)      # EVERY rank digests its whole band (eighths of the golden image)
+                digest = self.band_digests_match(f6, big, sh6, j6.d_out)      # EVERY rank digests its whole band (eighths of the golden image)
                 if digest is not None:
                     dflag = torch.tensor([1 if digest else 0], dtype=torch.int32, device=coll_dev)
                     dist.all_reduce(dflag, op=dist.ReduceOp.MIN)
@@ -670,7 +674,7 @@ def main():
                        "value_gpixel_s": round(big * big * args.steps / w6 / 1e9, 3), "ms_per_step": round(w6 / args.steps * 1e3, 5), "launch_us": round(ms6 * 1e3, 3),
                        "frac": round(j6.alg_bytes / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "verified_bit_exact_rows_min_over_ranks": int(v.item()),
                        "whole_band_digests_match_reference_all_ranks": digest}
-                row["gather"] = time_gathers(f6, big, sh6, j6.d_out, reps=1)
+                row["gather"] = self.time_gathers(f6, big, sh6, j6.d_out, reps=1)
                 extras["bc6h_32768"] = row
                 del j6
             except Exception as e:  # noqa
@@ -678,55 +682,60 @@ def main():
         torch.cuda.empty_cache()
         # (b) weak scaling: one 8192^2 image per rank
         if strong:
-            wjob = Job(fmt, args.size, args.size, make_input(fmt, args.size // 4, args.size // 4, args.stream if args.stream != "C" else "U", rank), args.layout, args.target)
-            w_wall, w_ms = timed(wjob, args.steps, args.warmup)
+            wjob = self.new_job(fmt, args.size, args.size, self.make_input(fmt, args.size // 4, args.size // 4, args.stream if args.stream != "C" else "U", rank), args.layout, args.target)
+            w_wall, w_ms = self.timed(wjob, args.steps, args.warmup)
             extras["weak"] = {"workload": "%s %dx%d per GPU" % (fmt.name, args.size, args.size), "value_gpixel_s": round(world * args.size * args.size * args.steps / w_wall / 1e9, 3),
                               "ms_per_step": round(w_wall / args.steps * 1e3, 5), "launch_us": round(w_ms * 1e3, 3)}
             del wjob
 
-    if rank != 0:
-        if multi:
-            dist.destroy_process_group()
-        return
+    def headline_result(self):
+        """the contract's keys"""
+        args, world, fmt, strong, W, H, job, cold, settle_us, settle_launches, wall, launch_ms, gpix, achieved, verified_rows, extras = self.args, self.world, self.fmt, self.strong, self.W, self.H, self.job, self.cold, self.settle_us, self.settle_launches, self.wall, self.launch_ms, self.gpix, self.achieved, self.verified_rows, self.extras
+        tname = F.PIXEL_FORMAT_NAMES.get(job.pf, "0x%04X" % job.pf)
+        if strong:
+            workload = ("%s->%s, ONE %dx%d image (stream %s, splitmix64 seed 0xD37E5000+k) sharded by block rows over %d GPU(s): "
+                        "one %d-row band per GPU, one launch per step, no data-path collective" % (fmt.name, tname, strong, strong, args.stream, world, H))
+        else:
+            workload = ("%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, one image per GPU"
+                        % (fmt.name, tname, W, H, args.stream))
+        result = {
+            "metric": "Gpixel/s decoded (%s -> %s, %s, device-resident)" % (fmt.name, tname, ("%dx%d image over %d GPU(s)" % (strong, strong, world)) if strong else "%dx%d per GPU" % (W, H)),
+            "value": round(gpix, 3), "unit": "Gpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": job.blocks, "stream": args.stream,
+                       "kernel": binding.kernel_name(fmt) if args.layout == "linear" else "decode_blocks", "layout": args.layout, "variant": args.variant,
+                       "target_pixel_format": "0x%04X" % job.pf},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": job.alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
+                         "write_frac": round(job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "note": "frac = algorithmic bytes (blocks read once + pixels written once) / launch time / 8 TB/s.  The timed loop decodes ONE input again and "
+                                 "again, so the blocks' share of those bytes is re-read from the 256 MiB memory-side Infinity Cache, not from HBM: write_frac is the HBM "
+                                 "part of this loop, blocks_from_hbm.frac the same launch with every byte through HBM (DESIGN.md section 4)"},
+            "verified_bit_exact_rows": verified_rows,
+            "settle": {"launches_before_warmup": settle_launches, "last_window_us": None if settle_us is None else round(settle_us, 3),
+                       "note": "untimed launches before the W warm-up steps, until two 100-launch windows agree within 1.2 % and >= 600 ran (--no-settle: none)"},
+        }
+        if cold:
+            result["cold"] = cold
+        if verified_rows == 0 or extras.get("whole_band_digests_match_reference_all_ranks") is False:
+            log("bench.py: OUTPUT MISMATCH against the oracle / the reference's band digests")
+            result["value"] = 0.0
+        return result
 
-    tname = F.PIXEL_FORMAT_NAMES.get(job.pf, "0x%04X" % job.pf)
-    if strong:
-        workload = ("%s->%s, ONE %dx%d image (stream %s, splitmix64 seed 0xD37E5000+k) sharded by block rows over %d GPU(s): "
-                    "one %d-row band per GPU, one launch per step, no data-path collective" % (fmt.name, tname, strong, strong, args.stream, world, H))
-    else:
-        workload = ("%s->%s %dx%d block stream %s (splitmix64 seed 0xD37E5000+k), one launch per step, one image per GPU"
-                    % (fmt.name, tname, W, H, args.stream))
-    result = {
-        "metric": "Gpixel/s decoded (%s -> %s, %s, device-resident)" % (fmt.name, tname, ("%dx%d image over %d GPU(s)" % (strong, strong, world)) if strong else "%dx%d per GPU" % (W, H)),
-        "value": round(gpix, 3), "unit": "Gpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": workload, "format": fmt.name, "width": W, "height_per_gpu": H, "blocks_per_gpu": job.blocks, "stream": args.stream,
-                   "kernel": binding.kernel_name(fmt) if args.layout == "linear" else "decode_blocks", "layout": args.layout, "variant": args.variant,
-                   "target_pixel_format": "0x%04X" % job.pf},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": job.alg_bytes, "launch_us": round(launch_ms * 1e3, 3),
-                     "write_frac": round(job.blocks * 16 * job.tpx / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-        "verified_bit_exact_rows": verified_rows,
-        "settle": {"launches_before_warmup": settle_launches, "last_window_us": None if settle_us is None else round(settle_us, 3),
-                   "note": "untimed launches before the W warm-up steps, until two 100-launch windows agree within 1.2 % and >= 600 ran (--no-settle: none)"},
-    }
-    if cold:
-        result["cold"] = cold
-    if verified_rows == 0 or extras.get("whole_band_digests_match_reference_all_ranks") is False:
-        log("bench.py: OUTPUT MISMATCH against the oracle / the reference's band digests")
-        result["value"] = 0.0
-    if not multi and not args.no_extras:
+    def add_roofline_references(self, result):
+        """N = 1: clock / power, the fill and copy references of this process, the same launch with its blocks coming out of HBM"""
+        args, telemetry, fmt, job, launch_ms, achieved = self.args, self.telemetry, self.fmt, self.job, self.launch_ms, self.achieved
         t = telemetry.during(job.step)
         torch.cuda.synchronize()
         if t:
             result["roofline"].update(t)
-        ref = hbm_reference(job)
+        ref = self.hbm_reference(job)
         result["roofline"].update(ref)
         if args.layout == "linear":
             try:
-                result["roofline"]["blocks_from_hbm"] = dict(blocks_from_hbm_row(job), note=(
+                result["roofline"]["blocks_from_hbm"] = dict(self.blocks_from_hbm_row(job), note=(
                     "the timed loop decodes ONE input again and again: its %d MiB of blocks are re-read from the 256 MiB memory-side Infinity Cache (which the L2's "
                     "EA counters behind `traffic` count as memory requests), HBM itself sees the pixel writes (`write_frac`).  Here the same launch over R different "
                     "inputs in turn, so that every launch's blocks come out of HBM; read_ahead_forced_*: with detexhipSetReadAhead(2) -- a read-only pass over the blocks, "
@@ -740,20 +749,26 @@ def main():
             result["roofline"]["frac_of_measured_fill"] = round(write_gbps / best_fill, 4)
         if ref.get("ref_copy_GBps"):
             result["roofline"]["frac_of_measured_copy"] = round(achieved / ref["ref_copy_GBps"], 4)
-    live = None
-    if not multi and not args.no_extras and not args.target and W == H and args.stream == "U":
-        live = live_pmc_traffic(fmt.name, W, args.layout)
-    if live:
-        result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
-        result["roofline"]["traffic_source"] = live["source"]
-        result["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_bytes", "write_bytes", "profiled_launches")}
-        result["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / job.alg_bytes, 4)
-    else:
-        t = pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
-        if t:
-            result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = "REPLAYED from profiles/pmc_traffic.json (no live counter pass in this run): " + str(t.get("source"))
-    if multi:
+
+    def add_traffic(self, result):
+        """HBM bytes per launch from rocprofv3 counter passes made now (or replayed from profiles/)"""
+        args, multi, fmt, W, H, job = self.args, self.multi, self.fmt, self.W, self.H, self.job
+        live = None
+        if not multi and not args.no_extras and not args.target and W == H and args.stream == "U":
+            live = live_pmc_traffic(fmt.name, W, args.layout)
+        if live:
+            result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = live["source"]
+            result["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_bytes", "write_bytes", "profiled_launches")}
+            result["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / job.alg_bytes, 4)
+        else:
+            t = self.pmc_traffic("%s/%d/%s" % (fmt.name, W, args.layout) + ("/%s" % args.target if args.target else ""))
+            if t:
+                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "REPLAYED from profiles/pmc_traffic.json (no live counter pass in this run): " + str(t.get("source"))
+
+    def add_collective_keys(self, result):
+        world, backend, rccl_ranks = self.world, self.backend, self.rccl_ranks
         result["rccl_ranks"] = rccl_ranks
         result["forced_dist_path"] = bool(world == 1)            # DETEX_BENCH_FORCE_DIST=1: the N > 1 code path at world size 1 (pre-flight, not a scaling point)
         try:
@@ -761,9 +776,10 @@ def main():
         except Exception:  # noqa
             result["rccl_version"] = None
         result["collective_backend"] = backend
-    result.update(extras)
 
-    if not multi:
+    def add_host_tier(self, result):
+        """host-pointer drop-in tier (PCIe-inclusive; never `value`)"""
+        args, fmt, W, H, data, job = self.args, self.fmt, self.W, self.H, self.data, self.job
         # host-pointer drop-in tier (PCIe-inclusive; never `value`)
         try:
             if args.layout != "linear":
@@ -779,35 +795,37 @@ def main():
         except Exception as e:  # noqa
             log("host tier timing failed:", e)
 
-    if not multi and not args.no_extras and not args.formats_json:
+    def add_per_format(self, result):
+        """per-format tables: the headline formats at 8192^2 (streams U / M / C) and the weakest kernels; the same formats and the narrow ones at 16384^2"""
+        args, job = self.args, self.job
         # per-format table of the headline formats (BASELINE configs[1..4]) at 8192^2, steady state, streams U / M / C
         table = {}
         t_start = time.perf_counter()
         for name in HEADLINE_FORMATS:
             f = F.BY_NAME[name]
             for kind in (["U", "M", "C"] if name in ("BPTC", "BPTC_FLOAT") else ["U", "C"]):
-                d = make_input(f, 2048, 2048, kind)
+                d = self.make_input(f, 2048, 2048, kind)
                 if d is None:
                     continue
-                j = Job(f, 8192, 8192, d)
-                us, launches = steady_state_us(j)
-                row = roofline_of(j, us)
+                j = self.new_job(f, 8192, 8192, d)
+                us, launches = self.steady_state_us(j)
+                row = self.roofline_of(j, us)
                 row["launches_before_reading"] = launches
-                tr = pmc_traffic("%s/8192/linear" % name)
+                tr = self.pmc_traffic("%s/8192/linear" % name)
                 if tr and kind == "U":
                     row["traffic"] = tr["hbm_bytes_per_launch"]
                 if kind == "U":
                     try:
-                        row["blocks_from_hbm"] = blocks_from_hbm_row(j)
+                        row["blocks_from_hbm"] = self.blocks_from_hbm_row(j)
                     except Exception as e:  # noqa
                         log("blocks_from_hbm failed:", name, e)
                 table["%s/%s" % (name, kind)] = row
                 del j
         for name, kind, layout in WEAK_KERNELS:
             f = F.BY_NAME[name]
-            j = Job(f, 8192, 8192, make_input(f, 2048, 2048, kind), layout)
-            us, launches = steady_state_us(j)
-            row = roofline_of(j, us)
+            j = self.new_job(f, 8192, 8192, self.make_input(f, 2048, 2048, kind), layout)
+            us, launches = self.steady_state_us(j)
+            row = self.roofline_of(j, us)
             row["launches_before_reading"] = launches
             table["%s/%s" % (name, kind) + ("/tiled" if layout == "tiled" else "")] = row
             del j
@@ -821,11 +839,11 @@ def main():
         for name in HEADLINE_FORMATS + NARROW_FORMATS:
             try:
                 f = F.BY_NAME[name]
-                j = Job(f, 16384, 16384, make_input(f, 4096, 4096, "U"))
-                us, launches = steady_state_us(j, window=25, max_windows=8, min_launches=100)
-                row = roofline_of(j, us)
+                j = self.new_job(f, 16384, 16384, self.make_input(f, 4096, 4096, "U"))
+                us, launches = self.steady_state_us(j, window=25, max_windows=8, min_launches=100)
+                row = self.roofline_of(j, us)
                 row["launches_before_reading"] = launches
-                tr = pmc_traffic("%s/16384/linear" % name)
+                tr = self.pmc_traffic("%s/16384/linear" % name)
                 if tr:
                     row["traffic"] = tr["hbm_bytes_per_launch"]
                     row["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / j.alg_bytes, 4)
@@ -851,6 +869,8 @@ def main():
             if best_fill:
                 row["frac_of_measured_fill"] = round(16384 * 16384 * job.tpx / (row["launch_us"] * 1e-6) / 1e9 / best_fill, 4)
             result["beyond_mall"] = row
+
+    def add_whole_images(self, result):
         # this GPU alone on the N > 1 workloads: the WHOLE 32768^2 image of BASELINE's strong-scaling configuration (BC1; configs[4]'s BC6H image
         # likewise) through ONE call of the device entry, so that the driver's N = 1 and N > 1 values divide without a footnote.  Beside it: the
         # same call with the library's read-ahead switched off (one launch: the blocks -- 512 MiB / 1 GiB, more than the 256 MiB Infinity
@@ -860,12 +880,12 @@ def main():
             try:
                 f = F.BY_NAME[name]
                 whole = sharding.shard_of(0, 1, f, 32768, 32768)
-                j = Job(f, 32768, 32768, band_stream(f, 32768, whole))
-                us, _ = steady_state_us(j, window=8, max_windows=6, min_launches=24, min_ms=20.0)
+                j = self.new_job(f, 32768, 32768, self.band_stream(f, 32768, whole))
+                us, _ = self.steady_state_us(j, window=8, max_windows=6, min_launches=24, min_ms=20.0)
                 verified = j.verify(16)
                 binding.set_read_ahead(False)
                 try:
-                    us_one, _ = steady_state_us(j, window=8, max_windows=6, min_launches=24, min_ms=20.0)
+                    us_one, _ = self.steady_state_us(j, window=8, max_windows=6, min_launches=24, min_ms=20.0)
                 finally:
                     binding.set_read_ahead(True)
                 row = {"workload": "%s 32768x32768 stream U, the whole image on this GPU in ONE detexhipDecompressTextureLinearDevice call" % name,
@@ -875,8 +895,8 @@ def main():
                        "one_launch_us": round(us_one, 1), "one_launch_frac": round(j.alg_bytes / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
                 del j
                 torch.cuda.empty_cache()
-                jb = Job(f, 32768, 8192, band_stream(f, 32768, sharding.shard_of(0, 4, f, 32768, 32768)))
-                us_b, _ = steady_state_us(jb, window=20, max_windows=6, min_launches=60)
+                jb = self.new_job(f, 32768, 8192, self.band_stream(f, 32768, sharding.shard_of(0, 4, f, 32768, 32768)))
+                us_b, _ = self.steady_state_us(jb, window=20, max_windows=6, min_launches=60)
                 row.update({"band_32768x8192_launch_us": round(us_b, 2), "band_frac": round(jb.alg_bytes / (us_b * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                             "band_note": "a quarter of the image decoded ALONE, repeatedly: its blocks stay in the Infinity Cache between repetitions, HBM sees writes only; "
                                          "four such bands of ONE image do not (DESIGN.md section 4)"})
@@ -887,7 +907,7 @@ def main():
                 result[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
 
-    if not multi and not args.no_extras:
+    def add_host_tier_small(self, result):
         # small inputs through the reference's own entry points (host pointers): where the PCIe-attached decoder loses to one
         # host thread.  Per call, including the ctypes call overhead on both sides (~2 us).
         try:
@@ -1006,31 +1026,99 @@ def main():
         except Exception as e:  # noqa
             log("host_tier_small failed:", e)
 
-    if not multi and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(fmt, data, W, H)
-
-    if args.formats_json and not multi:
+    def write_formats_table(self):
+        """--formats-json: every format x stream U / M / C at steady state, written to a file"""
+        args, W, H = self.args, self.W, self.H
         table = {}
         for f in F.FORMATS:
             for kind in ["U", "M", "C"]:
                 if kind == "M" and f.name not in ("BPTC", "BPTC_FLOAT", "BPTC_SIGNED_FLOAT"):
                     continue
-                d = make_input(f, W // 4, H // 4, kind)
+                d = self.make_input(f, W // 4, H // 4, kind)
                 if d is None:
                     continue
-                j = Job(f, W, H, d, args.layout)
-                us, launches = steady_state_us(j)
-                table["%s/%s" % (f.name, kind)] = roofline_of(j, us)
+                j = self.new_job(f, W, H, d, args.layout)
+                us, launches = self.steady_state_us(j)
+                table["%s/%s" % (f.name, kind)] = self.roofline_of(j, us)
                 log(f.name, kind, table["%s/%s" % (f.name, kind)])
                 del j
                 torch.cuda.empty_cache()
         os.makedirs(os.path.dirname(os.path.abspath(args.formats_json)), exist_ok=True)
         json.dump(table, open(args.formats_json, "w"), indent=1, sort_keys=True)
 
+    def run(self):
+        """-> the JSON line's dict on rank 0, None elsewhere"""
+        args, multi = self.args, self.multi
+        self.measure_headline()
+        if multi and not args.no_extras:
+            self.multi_gpu_extras()
+        if self.rank != 0:
+            return None
+        result = self.headline_result()
+        if not multi and not args.no_extras:
+            self.add_roofline_references(result)
+        self.add_traffic(result)
+        if multi:
+            self.add_collective_keys(result)
+        result.update(self.extras)
+        if not multi:
+            self.add_host_tier(result)
+            if not args.no_extras and not args.formats_json:
+                self.add_per_format(result)
+                self.add_whole_images(result)
+            if not args.no_extras:
+                self.add_host_tier_small(result)
+            if not args.no_cpu:
+                result["cpu_baseline"] = cpu_baseline(self.fmt, self.data, self.W, self.H)
+            if args.formats_json:
+                self.write_formats_table()
+        return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--format", default="BC1")
+    ap.add_argument("--size", type=int, default=8192, help="image width = per-rank height in pixels")
+    ap.add_argument("--band-height", type=int, default=0, help="per-rank band height if different from --size")
+    ap.add_argument("--strong-image", type=int, default=None,
+                    help="strong scaling: ONE S x S image sharded by block rows over the ranks; default 32768 (BASELINE "
+                         "north_star) when N > 1, off when N == 1")
+    ap.add_argument("--weak", action="store_true", help="N > 1: one --size^2 image per rank as the headline (round-1 behaviour)")
+    ap.add_argument("--variant", type=int, default=0, help="A/B kernel variant (needs DETEXHIP_LIB=<make lib-ab build>)")
+    ap.add_argument("--stream", default="U", choices=["U", "M", "C"])
+    ap.add_argument("--layout", default="linear", choices=["linear", "tiled"],
+                    help="linear = detexDecompressTextureLinear (headline); tiled = detexDecompressTextureTiled (block-major output)")
+    ap.add_argument("--target", default=None, help="target pixel format for the in-kernel epilogues: BGRA8, BGRX8, RGB8, FLOAT_BGRX16 (default: native)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-settle", action="store_true", help="start the contract's W + K launches cold (no settling launches before them)")
+    ap.add_argument("--no-extras", action="store_true", help="skip per_format / strong_image_32768 / weak / gather extras")
+    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is timed by default when N > 1)")
+    ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
+    args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Libraries print there too (gloo announces its connections, RCCL its version banner when
+    # NCCL_DEBUG is set, rocprofv3 its summary): from here on file descriptor 1 is stderr's, and the line at the end goes to the saved one.
     sys.stdout.flush()
-    real_stdout.write(json.dumps(result) + "\n")
-    real_stdout.flush()
-    if multi:
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    global torch, dist, binding, F, sharding, ol, streams
+    import torch
+    import torch.distributed as dist
+    from detex_amd import binding, formats as F, sharding
+    import oracle_lib as ol
+    import streams
+
+    bench = Bench(args)
+    result = bench.run()
+    if result is not None:
+        sys.stdout.flush()
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
+    if bench.multi:
         dist.destroy_process_group()
 
 

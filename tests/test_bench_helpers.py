@@ -72,3 +72,14 @@ def test_roofline_rows_claim_no_fraction_where_it_would_not_be_an_hbm_fraction(b
         for scale in (1, 4):
             row = bench.roofline_row(scale * blocks * 80, scale * blocks * 64, scale * 8192 * 8192, launch_us)
             assert row["frac"] is None or row["frac"] <= 1.0
+
+
+def test_bench_and_tools_have_no_undefined_names():
+    """bench.py cannot run without a GPU, and this image has no linter: tools/check_names.py walks every function of it (and of the GPU-side
+    measurement scripts) and reports names that are neither bound in an enclosing scope nor builtins -- what a typo in a rarely taken branch
+    of the driver's command would otherwise turn into a NameError on the GPU box"""
+    import subprocess, sys
+    files = ["bench.py", "__graft_entry__.py", "tools/gpu_rotating.py", "tools/gpu_run_case.py", "tools/gpu_time.py", "tools/pmc_traffic.py"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_names.py")] + [os.path.join(ROOT, f) for f in files], capture_output=True, text=True)
+    problems = [l for l in r.stdout.splitlines() if "undefined name __file__" not in l]
+    assert not problems, problems
