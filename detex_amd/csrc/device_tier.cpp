@@ -112,7 +112,7 @@ int current_read_ahead() {
 }
 
 int linear_device_with(uint32_t texture_format, const void *d_blocks, int width, int height, int width_in_blocks, int height_in_blocks,
-		void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant) {
+		void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant, int read_ahead) {
 	const FormatEntry *f = lookup_format(texture_format);
 	if (!f) { detexSetErrorMessage("detexhipDecompressTextureLinearDevice: 0x%08X is not a block-compressed format of this library", texture_format); return 1; }
 	if (!pixel_format_accepted(texture_format, pixel_format)) {
@@ -144,13 +144,13 @@ int linear_device_with(uint32_t texture_format, const void *d_blocks, int width,
 	// and HBM serves a read scattered among writes three times slower than a read from that cache (TCC_EA0_RDREQ_LEVEL / RDREQ: 2980 vs
 	// 1000 cycles; the whole 32768^2 BC1 image 815 us where its four quarters, decoded alone, take 4 x 163: profiles/r06/footprint/).
 	// Such textures go in bands of block rows -- a band is one contiguous range of blocks and of image rows, texture.c:115-141 -- each
-	// band's blocks read into the cache by a read-only pass first: a read phase and a write phase per band, on the caller's stream.
+	// band's blocks read into the cache by a read-only pass first: a read phase and a write phase per band, on the caller's stream -- for
+	// the formats where two phases beat the mixed stream (FormatEntry::read_ahead_pays: BC6H, BC1 / BC1A; launchers.h has the table).
 	const size_t bs = detexGetCompressedBlockSize(texture_format), row_bytes = (size_t)width_in_blocks * bs;
 	const bool whole_grid = (size_t)width_in_blocks * 4u == (size_t)width && (size_t)height_in_blocks * 4u == (size_t)height;
-	const int read_ahead = current_read_ahead();
 	const size_t block_bytes_total = row_bytes * (size_t)height_in_blocks;
 	if (whole_grid && row_bytes > 0 && row_bytes <= Tune::kReadAheadBandBytes &&
-			((read_ahead == 1 && block_bytes_total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && block_bytes_total >= ((size_t)1 << 20)))) {
+			((read_ahead == 1 && f->read_ahead_pays && block_bytes_total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && block_bytes_total >= ((size_t)1 << 20)))) {
 		const uint32_t band_rows = (uint32_t)(Tune::kReadAheadBandBytes / row_bytes);
 		for (uint32_t r0 = 0; r0 < (uint32_t)height_in_blocks; r0 += band_rows) {
 			const uint32_t rows = r0 + band_rows < (uint32_t)height_in_blocks ? band_rows : (uint32_t)height_in_blocks - r0;
@@ -211,7 +211,7 @@ extern "C" int detexhipDecompressTextureLinearDevice(uint32_t texture_format, co
 		int height, int width_in_blocks, int height_in_blocks, void *d_pixels, size_t pitch_bytes,
 		uint32_t pixel_format, void *stream, uint32_t *d_status) {
 	return linear_device_with(texture_format, d_blocks, width, height, width_in_blocks, height_in_blocks, d_pixels, pitch_bytes, pixel_format, stream, d_status,
-		current_spec_flags(), current_variant());
+		current_spec_flags(), current_variant(), current_read_ahead());
 }
 
 static int blocks_device(const char *who, uint32_t texture_format, const void *d_blocks, size_t n_blocks, uint32_t mode_mask,
@@ -230,7 +230,7 @@ static int blocks_device(const char *who, uint32_t texture_format, const void *d
 	// run of blocks (whole 256-block tiles) and the pixels behind the run before it
 	const size_t bs = detexGetCompressedBlockSize(texture_format), total = n_blocks * bs;
 	const int read_ahead = current_read_ahead();
-	if ((read_ahead == 1 && total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && total >= ((size_t)1 << 20))) {
+	if ((read_ahead == 1 && f->read_ahead_pays && total > Tune::kInfinityCacheBytes) || (read_ahead == 2 && total >= ((size_t)1 << 20))) {
 		const size_t band_blocks = (Tune::kReadAheadBandBytes / bs) & ~(size_t)255, out_per_block = 16u * (size_t)detexGetPixelSize(epilogue_target_of(texture_format, epi));
 		for (size_t b0 = 0; b0 < n_blocks; b0 += band_blocks) {
 			BatchArgs band = a;

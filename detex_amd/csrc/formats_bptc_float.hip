@@ -16,7 +16,7 @@ namespace detexhip {
 // (a function-local table: a namespace-scope const object would also be emitted into the device code object, where the launchers do not exist)
 const FormatEntry *formats_bptc_float() {
 	static const FormatEntry rows[2] = {
-		FMT(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 0), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
+		FMT_RA(BPTC_FLOAT, DecBPTCFloat, kClassBPTCFloat, 5, 0), FMT(BPTC_SIGNED_FLOAT, DecBPTCSignedFloat, kClassBPTCFloat, 0, 0),
 	};
 	return rows;
 }

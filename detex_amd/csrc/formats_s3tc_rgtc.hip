@@ -15,7 +15,7 @@ namespace detexhip {
 // (a function-local table: a namespace-scope const object would also be emitted into the device code object, where the launchers do not exist)
 const FormatEntry *formats_s3tc_rgtc() {
 	static const FormatEntry rows[8] = {
-		FMT(BC1, DecBC1, kClassS3TC, 0, 0), FMT(BC1A, DecBC1A, kClassS3TC, 0, 0), FMT(BC2, DecBC2, kClassS3TCat8, 5, 5), FMT(BC3, DecBC3, kClassS3TCat8, 5, 5),
+		FMT_RA(BC1, DecBC1, kClassS3TC, 0, 0), FMT_RA(BC1A, DecBC1A, kClassS3TC, 0, 0), FMT(BC2, DecBC2, kClassS3TCat8, 5, 5), FMT(BC3, DecBC3, kClassS3TCat8, 5, 5),
 		FMT_L(RGTC1, DecRGTC1, kClassNone, 0, 0, 5), FMT(SIGNED_RGTC1, DecSignedRGTC1, kClassNone, 0, 0), FMT(RGTC2, DecRGTC2, kClassNone, 6, 0),
 		FMT(SIGNED_RGTC2, DecSignedRGTC2, kClassNone, 0, 0),
 	};

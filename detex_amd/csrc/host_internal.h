@@ -70,6 +70,7 @@ struct FormatEntry {
 	int resident;			// resident workgroups per CU of the linear kernels (launchers.h: occupancy_cap_lds); 0 = whatever fits
 	int resident_blocks;		// the same for the block-major texture driver
 	int resident_beyond_cache;	// ... for the linear kernels when blocks + pixels exceed the Infinity Cache (Tune::kInfinityCacheBytes); -1 = the same as `resident`
+	bool read_ahead_pays;		// textures whose blocks exceed the Infinity Cache go in bands behind a read-ahead pass by default (device_tier.cpp; launchers.h: FMT_RA)
 };
 // format index (texture_format >> 24, detex.h:913-915): 1-8, 9-10, 11, 12-19
 const FormatEntry *formats_s3tc_rgtc(), *formats_bptc_float(), *formats_bptc(), *formats_etc_eac();	// 8, 2, 1, 8 rows (formats_*.hip)
@@ -93,10 +94,11 @@ uint32_t current_spec_flags();						// the decoders' kFlagSpec... bits for the c
 int max_variant();							// 0 in the product library
 extern int g_max_variant;					// (raised by the measurement build of tools/ab)
 
-// detexhipDecompressTextureLinearDevice with the quirk flags and kernel variant given explicitly instead of read from the calling
-// thread's settings: for worker threads that decode on behalf of a caller (multi_device.cpp)
+// detexhipDecompressTextureLinearDevice with the quirk flags, the kernel variant and the read-ahead mode given explicitly instead of read
+// from the calling thread's settings: for worker threads that decode on behalf of a caller (multi_device.cpp)
 int linear_device_with(uint32_t texture_format, const void *d_blocks, int width, int height, int width_in_blocks, int height_in_blocks,
-	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant);
+	void *d_pixels, size_t pitch_bytes, uint32_t pixel_format, void *stream, uint32_t *d_status, uint32_t decode_flags, int variant, int read_ahead);
+int current_read_ahead();						// 0 / 1 / 2 (detexhipSetReadAhead) of the calling thread
 
 // ---- 8f-4 (histogram.hip) ----------------------------------------------------------------------------------------------------------
 hipError_t launch_mode_histogram(int histogram_class, int block_dwords, const void *blocks, size_t n, uint32_t *hist, hipStream_t stream, bool zero_first);

@@ -206,8 +206,16 @@ template <class Dec> hipError_t launch_resident(const ResidentLaunch &r) {
 // RESIDENT_LARGE: the linear kernels' cap when blocks + pixels do not fit the 256 MiB Infinity Cache (-1: the same).  RGTC1 is the one
 // format where the two regimes want different answers (same-run sweep, round 5: 16384^2 -- 384 MiB -- no cap 59.2 us, three to five
 // per CU 55.3-55.5; 8192^2 -- 96 MiB, cache-resident -- no cap 12.4, capped 13.8-14.1): its stores are HBM-bound only when they reach HBM.
-#define FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
-	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE }
+// READ_AHEAD: whether a texture of this format whose BLOCKS exceed the Infinity Cache is decoded in bands behind a read-only pass by default
+// (detexhipSetReadAhead mode 1; device_tier.cpp).  Whole 32768^2 images, settled, one launch against the banded read-ahead
+// (profiles/r06/footprint/sweep_32768_settled.jsonl): BC6H 1646 -> 1546 us (two other boxes 1680 -> 1490, 1706 -> 1505), BC1 782 -> 754
+// (776 -> 749; 740 -> 752 on a third box) -- but BC3 783 -> 913, BC7 862 -> 948, ETC2_EAC 842 -> 901, signed BC6H 1595 -> 1618, ETC2 739 -> 744:
+// a kernel whose mixed read + write stream already runs at the additive bound (writes at their rate + the blocks at the HBM peak) can only
+// lose to a separate read pass at 5.7 TB/s.  So: BC6H and the BC1 pair, nothing else.
+#define FMT_ROW(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE, READ_AHEAD) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &launch_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
+	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE, READ_AHEAD }
+#define FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE) FMT_ROW(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE, false)
 #define FMT(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, -1)
+#define FMT_RA(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS) FMT_ROW(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, -1, true)
 
 }  // namespace detexhip

@@ -249,7 +249,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 	ShardSlots &slots = t_shards;
 	// the workers decode on behalf of the calling thread: ITS quirk mask and kernel variant apply, not the workers' own defaults
 	const uint32_t decode_flags = current_spec_flags();
-	const int variant = current_variant();
+	const int variant = current_variant(), read_ahead = current_read_ahead();
 	const auto t0 = std::chrono::steady_clock::now();
 	auto run = [&](int g) {
 		Work &w = work[g];
@@ -267,7 +267,7 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 		if ((e = hipMemsetAsync(sl.d_status, 0, 4, sl.stream)) != hipSuccess) { fail("hipMemsetAsync", e); return; }
 		if ((e = hipMemcpyAsync(sl.d_upload, static_cast<const uint8_t *>(host_blocks) + (size_t)row0 * wb * bs, n_in, hipMemcpyHostToDevice, sl.stream)) != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); return; }
 		if (linear_device_with(texture_format, sl.d_upload, width, (int)rows, width_in_blocks, row1 - row0, sl.d_band, row_bytes, pixel_format,
-				sl.stream, sl.d_status, decode_flags, variant) != 0) { snprintf(w.message, sizeof w.message, "%s", detexGetErrorMessage() ? detexGetErrorMessage() : "launch failed"); w.rc = 1; }
+				sl.stream, sl.d_status, decode_flags, variant, read_ahead) != 0) { snprintf(w.message, sizeof w.message, "%s", detexGetErrorMessage() ? detexGetErrorMessage() : "launch failed"); w.rc = 1; }
 		uint8_t *dst = static_cast<uint8_t *>(host_pixels) + y0 * pitch;
 		uint32_t st = 0;
 		if (w.rc == 0) {

@@ -247,8 +247,9 @@ DETEXHIP_API uint32_t detexhipGetQuirks(void);
  * blocks that sit in the GPU's 256 MiB memory-side cache (Infinity Cache) do not.  With read-ahead the texture is decoded in bands of block
  * rows, each band's blocks (at most 128 MiB) first read into that cache by a read-only pass -- several launches on the caller's stream
  * instead of one; same pixels, same status word.
- *   1 (default)  textures whose blocks alone exceed that cache and therefore cannot be resident in it (32768 x 32768 BC1: 512 MiB of
- *                blocks: 0.74 -> 0.82 of the HBM peak, BC6H 0.71 -> 0.80)
+ *   1 (default)  textures whose blocks alone exceed that cache and therefore cannot be resident in it, for the formats where two phases beat
+ *                the mixed stream: BPTC_FLOAT (32768 x 32768, 1 GiB of blocks: 0.71 -> 0.80 of the HBM peak) and BC1 / BC1A (512 MiB: 0.77 ->
+ *                0.80); the other formats' mixed stream already runs at what the memory allows, and they keep their single launch
  *   2            every texture with at least 1 MiB of blocks: for a caller who knows the blocks are NOT in the cache (freshly produced
  *                input, a stream of different textures); costs ~14 % where they are (a texture decoded again and again)
  *   0            never: always one launch

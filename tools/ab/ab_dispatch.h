@@ -96,6 +96,6 @@ static const int g_raise_variant_limit = (g_max_variant = 7);
 
 }  // namespace detexhip
 
-#undef FMT_L
-#define FMT_L(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &ab_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
-	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE }
+#undef FMT_ROW
+#define FMT_ROW(NAME, DEC, CLS, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE, READ_AHEAD) { #NAME, DETEX_TEXTURE_FORMAT_##NAME, &ab_linear<DEC>, &launch_blocks<DEC>, &launch_single<DEC>, \
+	&launch_levels<DEC>, &launch_resident<DEC>, CLS, "decode_linear<detexhip::" #DEC, RESIDENT, RESIDENT_BLOCKS, RESIDENT_LARGE, READ_AHEAD }

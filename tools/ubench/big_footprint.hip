@@ -111,10 +111,36 @@ template <int T, int RPOL, int WPOL, bool READ, bool WRITE> __global__ __launch_
 	}
 }
 
+// ---- "readpass": shapes of the read-only pass that brings a band's blocks into the Infinity Cache (the library's read_ahead kernel is the
+// 1024-lane / 4-loads-per-lane one) --------------------------------------------------------------------------------------------------------
+template <int LANES, int LOADS> __global__ __launch_bounds__(LANES) void read_pass(const v4 *__restrict__ p, uint64_t n_vectors) {
+	const uint64_t base = (uint64_t)blockIdx.x * (LANES * LOADS) + threadIdx.x;
+	v4 sink[LOADS];
+#pragma unroll
+	for (int k = 0; k < LOADS; k++) {
+		const uint64_t i = base + (uint64_t)LANES * (uint32_t)k;
+		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink[k]) : "v"(p + (i < n_vectors ? i : n_vectors - 1u)) : "memory");
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+	for (int k = 0; k < LOADS; k++) asm volatile("" :: "v"(sink[k]));
+}
+
 struct Timer {
 	hipStream_t stream;
 	hipEvent_t e0, e1;
 	Timer() { CHECK(hipStreamCreate(&stream)); CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); }
+	// the first ~12 ms of work after idle run through a power-management excursion (20-40 % slower for VALU-heavy kernels: DESIGN.md section 6):
+	// every experiment first keeps the device busy with its own first case for a while
+	template <class F> void settle(F &&fn, double ms = 60.0) {
+		CHECK(hipEventRecord(e0, stream));
+		for (;;) {
+			for (int k = 0; k < 4; k++) fn();
+			CHECK(hipEventRecord(e1, stream)); CHECK(hipEventSynchronize(e1));
+			float t = 0; CHECK(hipEventElapsedTime(&t, e0, e1));
+			if (t >= ms) break;
+		}
+	}
 	template <class F> double median_us(F &&fn, int warm = 3, int reps = 11) {
 		for (int k = 0; k < warm; k++) fn();
 		CHECK(hipStreamSynchronize(stream));
@@ -137,6 +163,10 @@ static const Fmt kFormats[] = {
 	{ "BC1", 0x01000320u, 0x0334u, 8, 4 },
 	{ "BPTC_FLOAT", 0x09802721u, 0x2721u, 16, 8 },
 	{ "BPTC", 0x0B800334u, 0x0334u, 16, 4 },
+	{ "BC3", 0x04800334u, 0x0334u, 16, 4 },
+	{ "ETC2", 0x0D000320u, 0x0320u, 8, 4 },
+	{ "ETC2_EAC", 0x0F800334u, 0x0334u, 16, 4 },
+	{ "BPTC_SIGNED_FLOAT", 0x0A803721u, 0x3721u, 16, 8 },
 };
 static const Fmt *format_named(const char *n) { for (const Fmt &f : kFormats) if (!strcmp(f.name, n)) return &f; fprintf(stderr, "unknown format %s\n", n); exit(2); }
 
@@ -163,6 +193,8 @@ static void sweep(const Fmt &f, int W, const std::vector<int> &heights, bool ext
 	CHECK(hipMalloc(&blocks, nb)); CHECK(hipMalloc(&pixels, np));
 	fill_random<<<4096, 256, 0, t.stream>>>(reinterpret_cast<uint32_t *>(blocks), nb / 4, 12345u);
 	CHECK(hipStreamSynchronize(t.stream));
+	detexhipSetReadAhead(0);
+	t.settle([&] { decode(f, blocks, pixels, W, heights[0], t.stream); });
 	for (int H : heights) {
 		// (one launch: the library's read-ahead banding of inputs beyond the Infinity Cache switched off; `readahead` = the entry as shipped)
 		detexhipSetReadAhead(0);
@@ -342,6 +374,29 @@ static void mix(int W) {
 	CHECK(hipFree(blocks)); CHECK(hipFree(pixels)); CHECK(hipFree(sink));
 }
 
+template <int LANES, int LOADS> static void read_pass_case(Timer &t, const uint8_t *buf, size_t total, size_t band) {
+	const uint64_t nv = band / 16u;
+	const unsigned grid = (unsigned)((nv + (uint64_t)LANES * LOADS - 1u) / ((uint64_t)LANES * LOADS));
+	size_t at = 0;
+	const double us = t.median_us([&] {		// a different band every launch: the reads come out of HBM
+		read_pass<LANES, LOADS><<<grid, LANES, 0, t.stream>>>(reinterpret_cast<const v4 *>(buf + at), nv);
+		at = (at + band) % total;
+	}, 4, 21);
+	printf("{\"exp\": \"readpass\", \"lanes\": %d, \"loads_per_lane\": %d, \"band_MiB\": %zu, \"us\": %.2f, \"TBps\": %.3f}\n", LANES, LOADS, band >> 20, us, (double)band / us * 1e-6);
+	fflush(stdout);
+}
+static void readpass() {
+	Timer t;
+	const size_t total = (size_t)1 << 30, band = (size_t)128 << 20;
+	uint8_t *buf; CHECK(hipMalloc(&buf, total));
+	fill_random<<<4096, 256, 0, t.stream>>>(reinterpret_cast<uint32_t *>(buf), total / 4, 99u);
+	CHECK(hipStreamSynchronize(t.stream));
+	read_pass_case<256, 2>(t, buf, total, band); read_pass_case<256, 4>(t, buf, total, band); read_pass_case<256, 8>(t, buf, total, band); read_pass_case<256, 16>(t, buf, total, band);
+	read_pass_case<512, 4>(t, buf, total, band); read_pass_case<512, 8>(t, buf, total, band);
+	read_pass_case<1024, 2>(t, buf, total, band); read_pass_case<1024, 4>(t, buf, total, band); read_pass_case<1024, 8>(t, buf, total, band);
+	CHECK(hipFree(buf));
+}
+
 int main(int argc, char **argv) {
 	const char *mode = argc > 1 ? argv[1] : "sweep";
 	if (!strcmp(mode, "sweep")) {
@@ -352,6 +407,8 @@ int main(int argc, char **argv) {
 		sweep(*f, 32768, heights, false);
 	} else if (!strcmp(mode, "mock")) {
 		mock(32768);
+	} else if (!strcmp(mode, "readpass")) {
+		readpass();
 	} else if (!strcmp(mode, "mix")) {
 		mix(32768);
 	} else if (!strcmp(mode, "pmc")) {
@@ -365,7 +422,7 @@ int main(int argc, char **argv) {
 		for (int k = 0; k < 5; k++) { if (band > 0) decode_banded(*f, blocks, pixels, W, H, band, t.stream); else decode(*f, blocks, pixels, W, H, t.stream); }
 		CHECK(hipStreamSynchronize(t.stream));
 	} else {
-		fprintf(stderr, "usage: big_footprint sweep FMT [H ...] | mock | mix | pmc FMT H [band]\n");
+		fprintf(stderr, "usage: big_footprint sweep FMT [H ...] | mock | mix | readpass | pmc FMT H [band]\n");
 		return 2;
 	}
 	return 0;
