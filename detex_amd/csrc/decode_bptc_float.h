@@ -406,6 +406,10 @@ template <bool SIGNED, bool SWITCH_SCATTER = false> struct DecBPTCFloatT {
 	static constexpr int kBlockBytes = 16, kPixelBytes = 8, kNative = SIGNED ? kNatOther : kNatFloatRGBX16;
 	static constexpr int kWavesPerSimd = Tune::kBc6hWavesPerSimd;
 	static constexpr bool kRowWise = true;
+	// the linear kernel requests the block BEFORE the tables are copied into LDS (kernels.h: LoadBeforeTables): with the blocks coming out of
+	// HBM the unsigned format gains 4 % (107.2 -> 102.8-103.4 us, 8192^2, two runs) and nothing changes where they come from the Infinity
+	// Cache (86.2 / 86.0); the signed format loses 8 % to the same change (102.5 -> 111), as do the RGTC / EAC formats with tables
+	static constexpr bool kLoadBeforeTables = !SIGNED;
 	static DH void prepare() { bc6h_prepare(); }
 
 	// decompress-bptc-float.c:110-626

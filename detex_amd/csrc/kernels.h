@@ -45,6 +45,10 @@ template <class Dec> struct OwnStage<Dec, std::enable_if_t<Dec::kOwnStage>> { st
 template <class Dec, class = void> struct RowWise { static constexpr bool value = false; };
 template <class Dec> struct RowWise<Dec, std::enable_if_t<Dec::kRowWise>> { static constexpr bool value = true; };
 
+// decoders whose linear kernel requests the block before the format tables are copied (Dec::kLoadBeforeTables; default: after the copy's barrier)
+template <class Dec, class = void> struct LoadBeforeTables { static constexpr bool value = false; };
+template <class Dec> struct LoadBeforeTables<Dec, std::enable_if_t<Dec::kLoadBeforeTables>> { static constexpr bool value = true; };
+
 // blocks per lane in the linear fast path (Dec::kLaneBlocks; default 1): see decode_linear_grouped
 template <class Dec, class = void> struct LaneBlocks { static constexpr int value = 1; };
 template <class Dec> struct LaneBlocks<Dec, std::enable_if_t<(Dec::kLaneBlocks > 1)>> { static constexpr int value = Dec::kLaneBlocks; };
@@ -402,10 +406,17 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		uint32_t *__restrict__ status, uint32_t decode_flags) {
 	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
 	using Word = typename BlockWord<Dec::kBlockBytes>::type;
+	constexpr bool kEarly = Tune::kLoadBeforeTables || LoadBeforeTables<Dec>::value;	// (the Tune switch: every decoder, measurement builds)
+	Word early;
+	if constexpr (kEarly) {
+		const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+		early = reinterpret_cast<const Word *>(blocks)[i0 < n_blocks ? i0 : n_blocks - 1u];
+	}
 	prepare_tables<Dec>();
 	prepare_epilogue<Dec, EPI>();
 	// The block is loaded AFTER the table copy's barrier: requested before it, the barrier waits for the workgroup's slowest
-	// HBM round trip (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 in the same run).  The load is unconditional, with
+	// HBM round trip (SIGNED_RGTC2 46.7 -> 50.3 us, EAC_R11 24.3 -> 25.7 in the same run) -- except for the decoders that say
+	// otherwise (LoadBeforeTables: unsigned BC6H, whose long decode hides the wait and whose blocks out of HBM arrive 4 % sooner).  The load is unconditional, with
 	// the index clamped into the stream: a load under a branch makes the compiler wait for it at the end of the branch.
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	Word blk;
@@ -413,6 +424,8 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	if constexpr (Tune::kPrefetchTiles > 0) {	// MEASUREMENT BUILDS ONLY (Tune::kPrefetchTiles): the blocks of a later tile requested too, and dropped
 		const uint32_t j = i + (uint32_t)Tune::kPrefetchTiles * 256u;
 		load_with_read_ahead(reinterpret_cast<const Word *>(blocks) + (i < n_blocks ? i : n_blocks - 1u), reinterpret_cast<const Word *>(blocks) + (j < n_blocks ? j : n_blocks - 1u), blk, ahead);
+	} else if constexpr (kEarly) {
+		blk = early;
 	} else {
 		blk = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
 	}

@@ -41,6 +41,9 @@ struct ProductTune {
 	// decode_linear: every wave also requests the blocks of the tile this many tiles further on (a multiple of eight: the same XCD's L2) and
 	// never uses them -- a read-ahead inside the launch for blocks that come out of HBM (0 = none; measurement: profiles/AB_RECORD.md round 6)
 	static constexpr int kPrefetchTiles = 0;
+	// decode_linear: the block requested BEFORE the format tables are copied into LDS (and waited for behind that copy's barrier) instead of
+	// after it (measurement builds; the product loads after the barrier: profiles/AB_RECORD.md rounds 2 and 6)
+	static constexpr bool kLoadBeforeTables = false;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store

@@ -19,6 +19,7 @@
 #   rgtc1gN                 RGTC1 blocks per lane
 #   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
+#   loadfirst               decode_linear: the block requested before the table copy's barrier
 #   prefetchN               decode_linear: each wave also requests (and drops) the blocks N tiles further on
 #   wgN                     N resident workgroups per CU for every linear kernel (0 = no cap; default: the per-format table)
 #   sleepN                  s_sleep N between a wave's row stores (linear kernels)
@@ -54,6 +55,7 @@ for v in "$@"; do
       rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
       hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
+      loadfirst) body+="static constexpr bool kLoadBeforeTables = true; " ;;
       prefetch*) body+="static constexpr int kPrefetchTiles = ${k#prefetch}; " ;;
       wg*) body+="static constexpr int kWorkgroupsPerCu = ${k#wg}; " ;;
       sleep*) body+="static constexpr int kStoreSleep = ${k#sleep}; " ;;
