@@ -56,19 +56,23 @@ SRCS_HIP_AB := formats_s3tc_rgtc_ab formats_etc_eac_ab formats_bptc_ab formats_b
 lib-ab:
 	$(MAKE) lib LIB=$(LIB_AB) OBJDIR=build/obj_ab SRCS_HIP="$(SRCS_HIP_AB)"
 
-# the library's host code under AddressSanitizer + UndefinedBehaviorSanitizer with a main that calls every entry point with hostile
-# arguments (tests/test_sanitized_host.py); host code only is instrumented (-fno-gpu-sanitize)
-SANFLAGS := -O1 -g -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=all
-api-san:
+# the library's host code under AddressSanitizer + UndefinedBehaviorSanitizer with mains that call every entry point with hostile arguments /
+# end threads and the process with resident kernels alive (tests/test_sanitized_host.py).  CONTAINER ONLY: the GPU pool runs no sanitizer
+# builds, so the instrumentation flags live in tests/host_san/san.mk, which .gpurunignore keeps off the GPU box together with the
+# instrumented binaries; host code only is instrumented.  The GPU box runs the uninstrumented builds of the same programs (host-plain).
+-include tests/host_san/san.mk
+need-san:
+	@test -n "$(SANFLAGS)" || { echo "tests/host_san/san.mk is absent (GPU box): instrumented builds are made in the container only"; exit 1; }
+api-san: need-san
 	$(MAKE) tests/host_san/api_san OBJDIR=build/obj_san EXTRA_HIPFLAGS="$(SANFLAGS)"
 $(OBJDIR)/api_san_main.o: tests/host_san/api_san_main.cpp include/detex.h include/detexhip.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 tests/host_san/api_san: $(OBJDIR)/api_san_main.o $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -o $@ $^
-# thread / process / dlclose teardown of the host tier's per-thread state under the same sanitizers (tests/host_san/teardown_san_main.cpp):
-# the test main linked with the instrumented objects, and the same objects as a shared library for its dlclose mode
-teardown-san:
+# thread / process / dlclose teardown of the host tier's per-thread state (tests/host_san/teardown_san_main.cpp): the test main linked with
+# the instrumented objects, and the same objects as a shared library for its dlclose mode
+teardown-san: need-san
 	$(MAKE) tests/host_san/teardown_san tests/host_san/libdetexhip_san.so OBJDIR=build/obj_san EXTRA_HIPFLAGS="$(SANFLAGS)"
 $(OBJDIR)/teardown_san_main.o: tests/host_san/teardown_san_main.cpp include/detex.h include/detexhip.h
 	@mkdir -p $(OBJDIR)
@@ -77,6 +81,14 @@ tests/host_san/teardown_san: $(OBJDIR)/teardown_san_main.o $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -pthread -o $@ $^ -ldl
 tests/host_san/libdetexhip_san.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) $(EXTRA_HIPFLAGS) -shared -fPIC -o $@ $^
+# the same two programs WITHOUT instrumentation, linked against the product library like any client: what the GPU box runs
+# (tests/test_gpu_host_programs.py); its dlclose mode opens detex_amd/lib/libdetexhip.so itself
+PLAIN := tests/host_san/api_plain tests/host_san/teardown_plain
+host-plain: $(PLAIN)
+tests/host_san/api_plain: tests/host_san/api_san_main.cpp include/detex.h include/detexhip.h $(LIB)
+	g++ -std=c++17 -O1 -g -Wall -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib'
+tests/host_san/teardown_plain: tests/host_san/teardown_san_main.cpp include/detex.h include/detexhip.h $(LIB)
+	g++ -std=c++17 -O1 -g -Wall -DTEARDOWN_SAN_LINKED -pthread -o $@ $< -Ldetex_amd/lib -ldetexhip -Wl,-rpath,'$$ORIGIN/../../detex_amd/lib' -ldl
 
 # a plain C client of the drop-in boundary (tests/c_client/detex_client.c; tests/test_c_client.py runs it on the GPU box): gcc, this
 # repository's detex.h, -ldetexhip with an rpath to the library; where the reference's sources are present (build container) a second
@@ -96,6 +108,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san tests/host_san/teardown_san tests/host_san/libdetexhip_san.so $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/big_footprint tools/ubench/libhbmref.so
+	rm -rf $(LIB) $(LIB_AB) build/obj build/obj_ab build/obj_san tests/host_san/api_san tests/host_san/teardown_san tests/host_san/libdetexhip_san.so tests/host_san/ktx_san $(PLAIN) $(CLIENT) $(CLIENT)_refhdr $(CLIENT)_reflib tools/ubench/valu_rates tools/ubench/big_footprint tools/ubench/libhbmref.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib lib-ab api-san teardown-san c-client oracle ubench hbmref clean
+.PHONY: all lib lib-ab need-san api-san teardown-san ktx-san host-plain c-client oracle ubench hbmref clean

@@ -1,6 +1,6 @@
 // tests/host_san/api_san_main.cpp -- TEST-ONLY: the host side of libdetexhip (argument validation, error convention, the
-// conversion-table builder) compiled with AddressSanitizer + UndefinedBehaviorSanitizer (hipcc -fsanitize=address,undefined
-// -fno-gpu-sanitize: host code only) and called with hostile arguments.  Every call below must be REFUSED with an error
+// conversion-table builder) compiled with AddressSanitizer + UndefinedBehaviorSanitizer on the host code (flags: tests/host_san/san.mk;
+// container only -- the GPU box runs the uninstrumented build, `make host-plain`) and called with hostile arguments.  Every call below must be REFUSED with an error
 // message and must not touch memory it was not given; a sanitizer report aborts with a non-zero exit code.  Runs without a GPU
 // (calls that pass validation then fail with "no usable HIP device"), and with one.  Not part of the product.
 #include "../../include/detex.h"

@@ -1,9 +1,14 @@
 """Host-side code of the library under AddressSanitizer + UndefinedBehaviorSanitizer.
 
 The KTX loader (detex_amd/csrc/ktx_loader.cpp; reference: ktx.c:36-176) is the one part of the library that parses file
-content; it is compiled here with g++ -fsanitize=address,undefined (tests/host_san/ktx_san_main.cpp) and fed a corpus of
+content; it is compiled here with g++ and both sanitizers (tests/host_san/ktx_san_main.cpp, `make ktx-san`) and fed a corpus of
 hostile files: every truncation of a valid mip chain, header fields replaced by extreme values, the byte-swapped form, key /
-value sizes that point outside the file, and seeded random byte corruption.  Any sanitizer report fails the test."""
+value sizes that point outside the file, and seeded random byte corruption.  Any sanitizer report fails the test.
+
+CONTAINER ONLY.  The GPU pool runs no sanitizer builds: the instrumentation flags live in tests/host_san/san.mk, and that file, this
+module and the instrumented binaries are listed in .gpurunignore.  The uninstrumented builds of the same programs run on the GPU box
+(tests/test_gpu_host_programs.py); earlier in round 6, before the pool's rule, the instrumented ones ran there too
+(profiles/r06/api_san_gpu.txt; the teardown program's three endings in that round's GPU test log)."""
 import os
 import struct
 import subprocess
@@ -19,10 +24,7 @@ KTX_ID = bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A
 @pytest.fixture(scope="module")
 def ktx_san():
     exe = os.path.join(SAN, "ktx_san")
-    deps = [os.path.join(SAN, "ktx_san_main.cpp"), os.path.join(ROOT, "detex_amd", "csrc", "ktx_loader.cpp"), os.path.join(ROOT, "include", "detex.h")]
-    if not os.path.exists(exe) or any(os.path.getmtime(exe) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
-                               "-Wall", "-o", exe, deps[0]])
+    subprocess.check_call(["make", "-s", "-C", ROOT, "ktx-san"])
     return exe
 
 
@@ -81,7 +83,7 @@ def test_ktx_loader_survives_a_hostile_corpus(ktx_san, tmp_path):
 
 def test_entry_points_refuse_hostile_arguments_under_sanitizers():
     """tests/host_san/api_san_main.cpp: the host side of the library itself (argument validation of every entry point, the
-    error convention, the half-float table builder) built with hipcc -fsanitize=address,undefined -fno-gpu-sanitize (`make api-san`:
+    error convention, the half-float table builder) built with hipcc and both sanitizers on the host code (`make api-san`:
     every translation unit of the library, instrumented, linked with the test's main) and called with arguments that must be
     refused.  Works without a GPU (what passes validation then fails with "no usable HIP device").  The build takes about half a
     minute and is cached (make)."""
@@ -92,31 +94,17 @@ def test_entry_points_refuse_hostile_arguments_under_sanitizers():
     assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
 
 
-@pytest.mark.gpu
-def test_host_tier_under_sanitizers_on_the_gpu_box():
-    """the same instrumented binary WITH a device: after the refusals it decodes through the host tier -- a launch per call, the
-    resident service (requests, format switches, idle exits and restarts, release with an instance lingering), staged textures -- and
-    compares every answer with the launch path's; AddressSanitizer / UBSan watch the host code (host_tier.cpp, host_resident.cpp).
-    The binary is built by the CPU suite (`make api-san`) and travels to the GPU box with the tree."""
-    exe = os.path.join(SAN, "api_san")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "api-san"], stderr=subprocess.DEVNULL)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "0 problems, no sanitizer report" in r.stdout and "device part ran" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["threads", "exit", "dlclose"])
-def test_thread_and_process_teardown_under_sanitizers(mode):
-    """tests/host_san/teardown_san_main.cpp (`make teardown-san`, built by __graft_entry__.build()): threads decode through the host tier --
-    their resident service kernels alive, idle time 200 ms -- and exit WITHOUT detexhipReleaseThreadResources(); the process then returns
-    from main() with the main thread's resident kernel lingering (`threads`), leaves through exit() from a worker thread (`exit`), or
-    dlclose()s the instrumented library, opens and uses it again (`dlclose`).  No crash, no hang, no AddressSanitizer / UBSan report."""
+def test_teardown_program_under_sanitizers_without_a_device():
+    """tests/host_san/teardown_san_main.cpp instrumented (`make teardown-san`): in the container every mode must end in its "no HIP
+    device" exit (code 4) -- the library loaded, initialised as far as it goes, its statics and thread_local contexts torn down, no
+    sanitizer report.  With a device the uninstrumented build runs the real thing (tests/test_gpu_host_programs.py)."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "teardown-san"], stderr=subprocess.DEVNULL)
     exe = os.path.join(SAN, "teardown_san")
     lib = os.path.join(SAN, "libdetexhip_san.so")
-    if not os.path.exists(exe) or not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-j8", "-C", ROOT, "teardown-san"], stderr=subprocess.DEVNULL)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    r = subprocess.run([exe, mode] + ([lib] if mode == "dlclose" else []), capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0 and "teardown_san: ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-4000:])
+    for mode in ("threads", "dlclose"):
+        r = subprocess.run([exe, mode] + ([lib] if mode == "dlclose" else []), capture_output=True, text=True, env=env, timeout=300)
+        if r.returncode == 0:                                         # a box with a device: the real run
+            assert "teardown_san: ok" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])
+        else:
+            assert r.returncode == 4 and "no HIP device" in r.stdout and "Sanitizer" not in r.stderr, (r.returncode, r.stdout[-3000:], r.stderr[-4000:])
