@@ -402,8 +402,35 @@ class Bench:
         pf, tpx = self.target_of(fmt, target)
         return Job(fmt, W, H, data, layout, pf, tpx)
 
-    def blocks_from_hbm_row(self, job):
-        """launch time with the blocks coming out of HBM (rotating inputs), as shipped and with the read-ahead pass forced (detexhipSetReadAhead(2))"""
+    def fresh_blocks_us(self, rot, producer, steps=80):
+        """median launch time (HIP events around each launch alone) when the launch's blocks were WRITTEN right before it, on the same stream,
+        into the rotating buffer it reads: `upload` = a copy out of pinned host memory (a texture streamer's upload -> decode), `device_copy` =
+        a device-to-device copy (blocks produced on the GPU)"""
+        j = rot.job
+        src = j.d_blocks.cpu().pin_memory() if producer == "upload" else j.d_blocks.clone()
+
+        def once(k, events):
+            dst = rot.inputs[1 + k % (len(rot.inputs) - 1)]          # (inputs[0] is the job's own buffer: left alone)
+            dst.copy_(src, non_blocking=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            binding.decompress_linear_device(j.fmt, dst, j.W, j.H, out=j.d_out, status=j.status, pixel_format=j.pf)
+            e1.record()
+            if events is not None:
+                events.append((e0, e1))
+        for k in range(20):
+            once(k, None)
+        torch.cuda.synchronize()
+        ev = []
+        for k in range(steps):
+            once(k, ev)
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        return us[len(us) // 2]
+
+    def blocks_from_hbm_row(self, job, producers=False):
+        """launch time with the blocks coming out of HBM (rotating inputs), as shipped and with the read-ahead pass forced (detexhipSetReadAhead(2));
+        `producers`: also with the blocks written right before each launch by an upload / by a device copy (which of the two regimes a pipeline sees)"""
         rot = RotatingInputs(job)
         us, _ = self.steady_state_us(rot, window=60, max_windows=8, min_launches=240, min_ms=20.0)
         row = {"inputs": len(rot.inputs), "launch_us": round(us, 2), "frac": round(job.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
@@ -414,6 +441,15 @@ class Bench:
             binding.set_read_ahead(1)
         row["read_ahead_forced_launch_us"] = round(us2, 2)
         row["read_ahead_forced_frac"] = round(job.alg_bytes / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+        if producers:
+            try:
+                row["after_upload_launch_us"] = round(self.fresh_blocks_us(rot, "upload"), 2)
+                row["after_device_copy_launch_us"] = round(self.fresh_blocks_us(rot, "device_copy"), 2)
+                row["producers_note"] = ("median of 80 launches timed one by one, the launch's blocks written into its (rotating) input buffer right before it on the "
+                                         "same stream: uploaded blocks arrive as cold as any (DMA writes do not stay in the Infinity Cache), blocks copied by a kernel "
+                                         "are partly served from it (DESIGN.md section 4)")
+            except Exception as e:           # an extra; never the line
+                row["producers_note"] = "not measured: %s" % (str(e)[:200],)
         del rot
         torch.cuda.empty_cache()
         return row
@@ -735,7 +771,7 @@ class Bench:
         result["roofline"].update(ref)
         if args.layout == "linear":
             try:
-                result["roofline"]["blocks_from_hbm"] = dict(self.blocks_from_hbm_row(job), note=(
+                result["roofline"]["blocks_from_hbm"] = dict(self.blocks_from_hbm_row(job, producers=True), note=(
                     "the timed loop decodes ONE input again and again: its %d MiB of blocks are re-read from the 256 MiB memory-side Infinity Cache (which the L2's "
                     "EA counters behind `traffic` count as memory requests), HBM itself sees the pixel writes (`write_frac`).  Here the same launch over R different "
                     "inputs in turn, so that every launch's blocks come out of HBM; read_ahead_forced_*: with detexhipSetReadAhead(2) -- a read-only pass over the blocks, "

@@ -471,6 +471,41 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 	}
 }
 
+// MEASUREMENT BUILDS ONLY (Tune::kWideTilesPerGroup > 1): the 64-bit-pixel path of decode_linear with TILES consecutive tiles per workgroup.
+// All TILES blocks of a lane are requested before the table copy; the first tile waits for its block behind that copy's barrier as in the
+// product, the later ones found theirs long ago -- with the blocks out of HBM (read latency ~3000 cycles in the middle of the write stream)
+// only one tile in TILES pays the round trip, and the tables are copied once for TILES tiles.
+template <class Dec, int EPI, int TILES>
+__global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear_wide_tiles(const void *__restrict__ blocks,
+		uint8_t *__restrict__ pixels, uint32_t width_in_blocks, uint32_t n_blocks, uint64_t pitch,
+		uint32_t *__restrict__ status, uint32_t decode_flags) {
+	constexpr int ROW = EpilogueOf<Dec, EPI>::kRowDwords;
+	static_assert(ROW == 8, "64-bit pixels only");
+	using Word = typename BlockWord<Dec::kBlockBytes>::type;
+	const uint32_t i0 = blockIdx.x * (256u * TILES) + threadIdx.x;
+	Word blk[TILES];
+#pragma unroll
+	for (int t = 0; t < TILES; t++) {
+		const uint32_t i = i0 + 256u * t;
+		blk[t] = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
+	}
+	prepare_tables<Dec>();
+	prepare_epilogue<Dec, EPI>();
+#pragma unroll
+	for (int t = 0; t < TILES; t++) {
+		if (blockIdx.x * (256u * TILES) + 256u * t >= n_blocks) break;	// (uniform: the stream's last workgroup)
+		pin_block(blk[t]);
+		const uint32_t i = i0 + 256u * t;
+		const bool live = i < n_blocks;
+		uint32_t o[4 * ROW];
+		bool ok = true;
+		if (live) ok = decode_word<Dec, EPI, false>(blk[t], 0xFFFFFFFFu, decode_flags, o);
+		if (stores_enabled(o))
+			store_rows_wide_pixels(pixels, pitch, width_in_blocks, i - (threadIdx.x & 63u), n_blocks, live, o);
+		if (live) raise_status(!ok, status);
+	}
+}
+
 // ---- linear layout, any dword-aligned geometry: rows staged per workgroup, stores aligned to 64-byte sectors ---------------
 // A streaming store instruction whose 1 KiB run does not start on a 64-byte boundary leaves a partial sector at both ends, to
 // be completed by the neighbouring wave's store -- measured on this chip (tools/ubench/hbm_ref.hip, 256 MiB fill): runs at

@@ -113,6 +113,12 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 				return hipGetLastError();
 			}
 		}
+		if constexpr (kRow == 8 && Tune::kWideTilesPerGroup > 1) {		// MEASUREMENT BUILDS ONLY: several tiles per workgroup, blocks requested up front
+			constexpr auto kernel = &decode_linear_wide_tiles<Dec, EPI, Tune::kWideTilesPerGroup>;
+			hipLaunchKernelGGL(kernel, dim3((tiles + Tune::kWideTilesPerGroup - 1u) / Tune::kWideTilesPerGroup), dim3(256),
+				occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
+			return hipGetLastError();
+		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
 		constexpr auto kernel = &decode_linear<Dec, EPI, true>;
 		hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch,

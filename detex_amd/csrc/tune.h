@@ -44,6 +44,10 @@ struct ProductTune {
 	// decode_linear: the block requested BEFORE the format tables are copied into LDS (and waited for behind that copy's barrier) instead of
 	// after it (measurement builds; the product loads after the barrier: profiles/AB_RECORD.md rounds 2 and 6)
 	static constexpr bool kLoadBeforeTables = false;
+	// 64-bit pixels, linear layout: tiles (of 256 blocks) per workgroup, all of the workgroup's blocks requested before the table copy and the
+	// tiles then decoded and stored one after the other -- a software pipeline for blocks that come out of HBM (1 = the product's one tile per
+	// workgroup; measurement builds: profiles/AB_RECORD.md round 6)
+	static constexpr int kWideTilesPerGroup = 1;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store

@@ -21,6 +21,7 @@
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
 #   loadfirst               decode_linear: the block requested before the table copy's barrier
 #   prefetchN               decode_linear: each wave also requests (and drops) the blocks N tiles further on
+#   widetilesN              64-bit pixels, linear layout: N tiles per workgroup, all blocks requested before the table copy (product: 1)
 #   wgN                     N resident workgroups per CU for every linear kernel (0 = no cap; default: the per-format table)
 #   sleepN                  s_sleep N between a wave's row stores (linear kernels)
 #   planarN                 ETC2: most planar blocks per wave decoded cooperatively (0 = always in-lane)
@@ -57,6 +58,7 @@ for v in "$@"; do
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
       loadfirst) body+="static constexpr bool kLoadBeforeTables = true; " ;;
       prefetch*) body+="static constexpr int kPrefetchTiles = ${k#prefetch}; " ;;
+      widetiles*) body+="static constexpr int kWideTilesPerGroup = ${k#widetiles}; " ;;
       wg*) body+="static constexpr int kWorkgroupsPerCu = ${k#wg}; " ;;
       sleep*) body+="static constexpr int kStoreSleep = ${k#sleep}; " ;;
       planar*) body+="static constexpr int kEtcPlanarShared = ${k#planar}; " ;;
