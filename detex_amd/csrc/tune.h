@@ -48,6 +48,15 @@ struct ProductTune {
 	// tiles then decoded and stored one after the other -- a software pipeline for blocks that come out of HBM (1 = the product's one tile per
 	// workgroup; measurement builds: profiles/AB_RECORD.md round 6)
 	static constexpr int kWideTilesPerGroup = 1;
+	// 32-bit pixels, linear layout: a workgroup covers 64 blocks and wave w decodes and stores TEXEL ROW w of them -- one store per lane, every
+	// block decoded by four lanes (kernels.h: decode_linear_rowwave); measurement builds: profiles/AB_RECORD.md round 6
+	static constexpr bool kRowWave = false;
+	// ... and the cooperative form of that for the decoders that define Dec::RowSplit (BC1 / BC1A): wave 0 decodes what the block's texels share
+	// into LDS, then wave w picks and stores texel row w (kernels.h: decode_linear_rowsplit)
+	static constexpr bool kRowSplit = false;
+	static constexpr int kRowSplitPrefetch = 0;	// ... wave 1 also requests (and drops) the blocks of the workgroup this many workgroups further on
+	// decode_linear with ONE-WAVE workgroups (64 blocks, 4 KiB of 32-bit pixels per workgroup) for the decoders without format tables
+	static constexpr bool kOneWaveGroups = false;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store

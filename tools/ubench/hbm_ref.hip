@@ -63,6 +63,110 @@ template <int PATTERN> __global__ __launch_bounds__(256) void fill_image_kernel(
 		__builtin_nontemporal_store(make_vector<PATTERN>(blockIdx.x * 1024u + r * 256u + threadIdx.x, seed), p + (uint64_t)r * pitch_vectors);
 }
 
+// image layout with ONE store per lane.  SHAPE 0: a workgroup covers 64 vectors (1 KiB) of four image rows, wave w writing row w (the
+// decode kernels' tile with the texel rows dealt to the waves instead of to the lanes' registers); SHAPE 1: a workgroup writes 256
+// vectors (4 KiB) of ONE image row, workgroups in row-major order; SHAPE 2: as 0 but 128 lanes x 2 tiles (two stores per lane,
+// the wave's two runs 1 KiB apart in its row)
+template <int SHAPE, bool NT> __global__ __launch_bounds__(256) void fill_image_lane_kernel(v4 *__restrict__ dst, uint32_t pitch_vectors, uint32_t tiles_per_row, uint32_t seed) {
+	const uint32_t ty = blockIdx.x / tiles_per_row, tx = blockIdx.x - ty * tiles_per_row;
+	if (SHAPE == 0) {
+		v4 *p = dst + (uint64_t)(4u * ty + (threadIdx.x >> 6)) * pitch_vectors + (uint64_t)tx * 64u + (threadIdx.x & 63u);
+		const v4 v = make_vector<2>(blockIdx.x * 256u + threadIdx.x, seed);
+		if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+	} else if (SHAPE == 1) {
+		v4 *p = dst + (uint64_t)ty * pitch_vectors + (uint64_t)tx * 256u + threadIdx.x;
+		const v4 v = make_vector<2>(blockIdx.x * 256u + threadIdx.x, seed);
+		if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+	} else {
+		v4 *p = dst + (uint64_t)(4u * ty + (threadIdx.x >> 6)) * pitch_vectors + (uint64_t)tx * 128u + (threadIdx.x & 63u);
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const v4 v = make_vector<2>(blockIdx.x * 512u + k * 256u + threadIdx.x, seed);
+			if (NT) __builtin_nontemporal_store(v, p + 64 * k); else p[64 * k] = v;
+		}
+	}
+}
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_image_lane(void *dst, size_t width_bytes, size_t height, size_t pitch_bytes, int shape, int nontemporal, uint32_t seed, void *stream) {
+	if (pitch_bytes == 0) pitch_bytes = width_bytes;
+	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || pitch_bytes % 16u || pitch_bytes < width_bytes || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const uint32_t pitch_vectors = (uint32_t)(pitch_bytes / 16u);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+	const uint32_t per_row = (uint32_t)(width_bytes / (shape == 0 ? 1024u : shape == 1 ? 4096u : 2048u));
+	const dim3 grid((unsigned)(per_row * (shape == 1 ? height : height / 4u))), block(256);
+#define LANE_CASE(S) case S: if (nontemporal) hipLaunchKernelGGL((fill_image_lane_kernel<S, true>), grid, block, 0, s, d, pitch_vectors, per_row, seed); \
+	else hipLaunchKernelGGL((fill_image_lane_kernel<S, false>), grid, block, 0, s, d, pitch_vectors, per_row, seed); break;
+	switch (shape) { LANE_CASE(0) LANE_CASE(1) LANE_CASE(2) default: return 1; }
+#undef LANE_CASE
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// the decode kernels' own shape (every lane four stores, one per texel row) with LANES-wide workgroups; ROTATE: wave w starts with row w
+// (the four waves of a workgroup write four different rows at any moment)
+template <int LANES, bool ROTATE> __global__ __launch_bounds__(LANES) void fill_image_group_kernel(v4 *__restrict__ dst, uint32_t pitch_vectors, uint32_t tiles_per_row, uint32_t seed) {
+	const uint32_t ty = blockIdx.x / tiles_per_row, tx = blockIdx.x - ty * tiles_per_row;
+	v4 *p = dst + (uint64_t)(4u * ty) * pitch_vectors + (uint64_t)tx * LANES + threadIdx.x;
+	const uint32_t w = ROTATE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint32_t row = (r + w) & 3u;
+		__builtin_nontemporal_store(make_vector<2>(blockIdx.x * (4u * LANES) + r * LANES + threadIdx.x, seed), p + (uint64_t)row * pitch_vectors);
+	}
+}
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_image_group(void *dst, size_t width_bytes, size_t height, int lanes, int rotate, uint32_t seed, void *stream) {
+	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const uint32_t pitch_vectors = (uint32_t)(width_bytes / 16u), per_row = (uint32_t)(width_bytes / (16u * lanes));
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+	const dim3 grid((unsigned)(per_row * (height / 4u)));
+	if (lanes == 64) hipLaunchKernelGGL((fill_image_group_kernel<64, false>), grid, dim3(64), 0, s, d, pitch_vectors, per_row, seed);
+	else if (lanes == 128) hipLaunchKernelGGL((fill_image_group_kernel<128, false>), grid, dim3(128), 0, s, d, pitch_vectors, per_row, seed);
+	else if (lanes == 256 && rotate) hipLaunchKernelGGL((fill_image_group_kernel<256, true>), grid, dim3(256), 0, s, d, pitch_vectors, per_row, seed);
+	else if (lanes == 256) hipLaunchKernelGGL((fill_image_group_kernel<256, false>), grid, dim3(256), 0, s, d, pitch_vectors, per_row, seed);
+	else return 1;
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// shape 0 of fill_image_lane_kernel (wave w = texel row w of a 64-vector tile, one store per lane per tile) on a PERSISTENT grid: workgroups loop
+// over tiles b, b + gridDim.x, ...  SYNC 0: nothing between iterations; 1: a workgroup barrier; 2: the wave waits for its store's acknowledgement
+// (s_waitcnt vmcnt(0)) before the next one.  And FOUR: the decode kernels' four-stores-per-lane tile with that wait between the stores (grid = tiles).
+template <int SYNC> __global__ __launch_bounds__(256) void fill_image_lane_persistent_kernel(v4 *__restrict__ dst, uint32_t pitch_vectors, uint32_t tiles_per_row, uint32_t n_tiles, uint32_t seed) {
+	for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+		const uint32_t ty = t / tiles_per_row, tx = t - ty * tiles_per_row;
+		v4 *p = dst + (uint64_t)(4u * ty + (threadIdx.x >> 6)) * pitch_vectors + (uint64_t)tx * 64u + (threadIdx.x & 63u);
+		__builtin_nontemporal_store(make_vector<2>(t * 256u + threadIdx.x, seed), p);
+		if (SYNC == 1) __syncthreads();
+		if (SYNC == 2) __builtin_amdgcn_s_waitcnt(0x0F70);	// vmcnt(0) on gfx9 encodings: lgkmcnt / expcnt left at their maxima
+	}
+}
+__global__ __launch_bounds__(256) void fill_image_four_waited_kernel(v4 *__restrict__ dst, uint32_t pitch_vectors, uint32_t tiles_per_row, uint32_t seed) {
+	const uint32_t ty = blockIdx.x / tiles_per_row, tx = blockIdx.x - ty * tiles_per_row;
+	v4 *p = dst + (uint64_t)(4u * ty) * pitch_vectors + (uint64_t)tx * 256u + threadIdx.x;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		__builtin_nontemporal_store(make_vector<2>(blockIdx.x * 1024u + r * 256u + threadIdx.x, seed), p + (uint64_t)r * pitch_vectors);
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+	}
+}
+extern "C" __attribute__((visibility("default"))) int hbmref_fill_image_persistent(void *dst, size_t width_bytes, size_t height, int sync, int groups, uint32_t seed, void *stream) {
+	if (width_bytes == 0 || height == 0 || width_bytes % 4096u || height % 4u || (reinterpret_cast<uintptr_t>(dst) & 15u)) return 1;
+	const uint32_t pitch_vectors = (uint32_t)(width_bytes / 16u);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	v4 *d = static_cast<v4 *>(dst);
+	if (sync == 4) {
+		const uint32_t per_row = (uint32_t)(width_bytes / 4096u);
+		hipLaunchKernelGGL(fill_image_four_waited_kernel, dim3((unsigned)(per_row * (height / 4u))), dim3(256), 0, s, d, pitch_vectors, per_row, seed);
+		return hipGetLastError() == hipSuccess ? 0 : 1;
+	}
+	const uint32_t per_row = (uint32_t)(width_bytes / 1024u), n_tiles = per_row * (uint32_t)(height / 4u);
+	const dim3 grid((unsigned)groups), block(256);
+	if (sync == 0) hipLaunchKernelGGL((fill_image_lane_persistent_kernel<0>), grid, block, 0, s, d, pitch_vectors, per_row, n_tiles, seed);
+	else if (sync == 1) hipLaunchKernelGGL((fill_image_lane_persistent_kernel<1>), grid, block, 0, s, d, pitch_vectors, per_row, n_tiles, seed);
+	else if (sync == 2) hipLaunchKernelGGL((fill_image_lane_persistent_kernel<2>), grid, block, 0, s, d, pitch_vectors, per_row, n_tiles, seed);
+	else return 1;
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // the linear fill with ROWS vectors per lane (ROWS = 1: a workgroup writes 4 KiB and every wave issues ONE store, the shape of
 // torch's fill kernel)
 // WAVE_CONTIGUOUS: a wave's ROWS stores cover ROWS consecutive KiB (instead of one KiB in each of ROWS 4 KiB pieces)
