@@ -135,6 +135,26 @@ template <int POLICY, int DWORDS, class V, class P> DH void store_with_policy(V 
 	}
 }
 
+// MEASUREMENT BUILDS ONLY (Tune::kLoadPolicy): the block load with an explicit cache policy (bits as for the stores), waited for at once
+template <int POLICY> DH void load_with_policy(const uint2 *p, uint2 &blk) {
+	u32x2 b;
+#define DETEXHIP_LOAD(BITS) asm volatile("global_load_dwordx2 %0, %1, off " BITS "\n\ts_waitcnt vmcnt(0)" : "=&v"(b) : "v"(p) : "memory")
+	if constexpr (POLICY == 1) { DETEXHIP_LOAD("sc0"); } else if constexpr (POLICY == 2) { DETEXHIP_LOAD("sc1"); } else if constexpr (POLICY == 3) { DETEXHIP_LOAD("sc0 sc1"); }
+	else if constexpr (POLICY == 4) { DETEXHIP_LOAD("nt"); } else if constexpr (POLICY == 5) { DETEXHIP_LOAD("sc0 nt"); } else if constexpr (POLICY == 6) { DETEXHIP_LOAD("sc1 nt"); }
+	else { DETEXHIP_LOAD("sc0 sc1 nt"); }
+#undef DETEXHIP_LOAD
+	blk = uint2{ b.x, b.y };
+}
+template <int POLICY> DH void load_with_policy(const uint4 *p, uint4 &blk) {
+	u32x4 b;
+#define DETEXHIP_LOAD(BITS) asm volatile("global_load_dwordx4 %0, %1, off " BITS "\n\ts_waitcnt vmcnt(0)" : "=&v"(b) : "v"(p) : "memory")
+	if constexpr (POLICY == 1) { DETEXHIP_LOAD("sc0"); } else if constexpr (POLICY == 2) { DETEXHIP_LOAD("sc1"); } else if constexpr (POLICY == 3) { DETEXHIP_LOAD("sc0 sc1"); }
+	else if constexpr (POLICY == 4) { DETEXHIP_LOAD("nt"); } else if constexpr (POLICY == 5) { DETEXHIP_LOAD("sc0 nt"); } else if constexpr (POLICY == 6) { DETEXHIP_LOAD("sc1 nt"); }
+	else { DETEXHIP_LOAD("sc0 sc1 nt"); }
+#undef DETEXHIP_LOAD
+	blk = uint4{ b.x, b.y, b.z, b.w };
+}
+
 // A block load with a second, never-used load of the same width issued right behind it (a read-ahead: `ahead` is only wanted in the
 // caches).  Loads return in order, so the wait is for all but the last one: the block is there, the read-ahead still travelling.  The
 // compiler does not know about that outstanding load: the caller keeps `sink` alive to the end of the kernel (keep_alive) so that its

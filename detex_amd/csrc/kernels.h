@@ -429,6 +429,8 @@ __global__ __launch_bounds__(256, WavesPerSimd<Dec>::value) void decode_linear(c
 		load_with_read_ahead(reinterpret_cast<const Word *>(blocks) + (i < n_blocks ? i : n_blocks - 1u), reinterpret_cast<const Word *>(blocks) + (j < n_blocks ? j : n_blocks - 1u), blk, ahead);
 	} else if constexpr (kEarly) {
 		blk = early;
+	} else if constexpr (Tune::kLoadPolicy != 0) {	// MEASUREMENT BUILDS ONLY
+		load_with_policy<Tune::kLoadPolicy>(reinterpret_cast<const Word *>(blocks) + (i < n_blocks ? i : n_blocks - 1u), blk);
 	} else {
 		blk = reinterpret_cast<const Word *>(blocks)[i < n_blocks ? i : n_blocks - 1u];
 	}

@@ -57,6 +57,8 @@ struct ProductTune {
 	static constexpr int kRowSplitPrefetch = 0;	// ... wave 1 also requests (and drops) the blocks of the workgroup this many workgroups further on
 	// decode_linear with ONE-WAVE workgroups (64 blocks, 4 KiB of 32-bit pixels per workgroup) for the decoders without format tables
 	static constexpr bool kOneWaveGroups = false;
+	// decode_linear: cache policy of the block load (bits as for the stores; 0 = the compiler's plain load)
+	static constexpr int kLoadPolicy = 0;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)
 	static constexpr int kStoreSleep = 0;
 	// cache policy of the row stores of the linear kernels (bit 0 sc0, bit 1 sc1, bit 2 nt; 4 = what __builtin_nontemporal_store

@@ -19,6 +19,7 @@
 #   rgtc1gN                 RGTC1 blocks per lane
 #   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
+#   loadpolicyN             decode_linear: cache policy of the block load (bit 0 sc0, bit 1 sc1, bit 2 nt)
 #   loadfirst               decode_linear: the block requested before the table copy's barrier
 #   prefetchN               decode_linear: each wave also requests (and drops) the blocks N tiles further on
 #   rowsplit                BC1 / BC1A, linear layout, native target: wave 0 of a 64-block workgroup decodes the palettes into LDS, wave w picks and stores texel row w
@@ -59,6 +60,7 @@ for v in "$@"; do
       rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
       hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
+      loadpolicy*) body+="static constexpr int kLoadPolicy = ${k#loadpolicy}; " ;;
       loadfirst) body+="static constexpr bool kLoadBeforeTables = true; " ;;
       prefetch*) body+="static constexpr int kPrefetchTiles = ${k#prefetch}; " ;;
       rowsplitpf*) body+="static constexpr bool kRowSplit = true; static constexpr int kRowSplitPrefetch = ${k#rowsplitpf}; " ;;
