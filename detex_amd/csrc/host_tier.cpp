@@ -6,7 +6,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "host_internal.h"
@@ -87,6 +89,9 @@ struct ThreadContext {
 	// small calls: a pinned host buffer the kernels read blocks from and write pixels / status into directly (see direct_exchange)
 	uint8_t *h_pin = nullptr, *d_pin = nullptr;
 	size_t pin_cap = 0;
+	// large calls: a second stream and one event per band for the uploads that run beside the downloads (via_staging_duplex); created on first use
+	hipStream_t stream_up = nullptr;
+	hipEvent_t ev_up[Tune::kHostDuplexBands] = {};
 	ResidentService service;	// the smallest calls, from the second in a row of one (format, target) pair on (host_resident.cpp)
 	void release() {
 		if (!ready) return;
@@ -95,6 +100,12 @@ struct ThreadContext {
 		(void)hipSetDevice(device);
 		service.release();
 		(void)hipStreamSynchronize(stream);
+		if (stream_up) {
+			(void)hipStreamSynchronize(stream_up);
+			for (hipEvent_t &e : ev_up) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+			(void)hipStreamDestroy(stream_up);
+			stream_up = nullptr;
+		}
 		(void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_status);
 		if (h_pin) (void)hipHostFree(h_pin);
 		(void)hipStreamDestroy(stream);
@@ -167,7 +178,8 @@ bool heal_if_dirty() {
 	if (!c.dirty) return true;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
-	if (hipStreamSynchronize(c.stream) != hipSuccess || hipMemset(c.d_status, 0, kStatusWords * sizeof(uint32_t)) != hipSuccess) {
+	if ((c.stream_up && hipStreamSynchronize(c.stream_up) != hipSuccess) || hipStreamSynchronize(c.stream) != hipSuccess ||
+			hipMemset(c.d_status, 0, kStatusWords * sizeof(uint32_t)) != hipSuccess) {
 		(void)hipGetLastError();
 		c.release();
 		return context_ready();
@@ -537,6 +549,82 @@ struct TextureCall {
 	// 4.8 ms, upload 0.6 ms, kernel 0.04 ms.  A band pipeline -- upload k+1 | kernel k | download k-1 on three streams -- was built and
 	// measured in round 2: 5.40 vs 5.45 ms, a download that shares the link with an upload runs at 41-50 GB/s; two bands on two streams
 	// at 1024^2 in round 5: 135 vs 121 us.  Neither was kept.)
+	// Large textures: upload and download at the same time.  The link is full duplex, but a copy between PAGEABLE memory and the device blocks the
+	// thread that asks for it (the "async" call returns when the copy is done: profiles/r05/host_paths.txt) -- so a helper thread uploads the
+	// blocks band by band (block rows) on a second stream, recording an event per band, while this thread, band by band, makes its stream wait
+	// for the band's event, launches the band's decode and downloads the band's pixels.  Whole-block geometries only (every band is then a
+	// texture of its own to the device entry); the status word is shared by the bands' launches and read once at the end.
+	Outcome via_staging_duplex() const {
+		constexpr int B = Tune::kHostDuplexBands;
+		// (worth it from about 16 MiB of blocks on -- 0.3 ms of upload to hide: BC1 4096^2, 8 MiB, loses 0.2 ms to the helper thread and the eight bands)
+		if (Tune::kHostDuplexBytes == 0 || out_bytes < Tune::kHostDuplexBytes || in_bytes < Tune::kHostDuplexBytes / 2 || hb < (size_t)(2 * B)) return kNotTaken;
+		if (!tiled && !(width == 4u * wb && height == 4u * hb)) return kNotTaken;
+		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
+		if (!c.stream_up) {
+			if (!try_hip(hipStreamCreateWithFlags(&c.stream_up, hipStreamNonBlocking), "hipStreamCreate")) { c.stream_up = nullptr; return kFalse; }
+			for (hipEvent_t &e : c.ev_up)
+				if (!try_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) { e = nullptr; return kFalse; }
+		}
+		DirectExchange x;
+		if (!direct_exchange(c, 0, 0, &x)) return kFalse;
+		if (!reserve(&c.d_out, &c.out_cap, out_bytes) || !reserve(&c.d_in, &c.in_cap, in_bytes)) return kFalse;
+		const bool pinned_status = wb * hb <= ((size_t)1 << 20);
+		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);
+		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
+		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
+		c.dirty = true;
+		const uint8_t *src = static_cast<const uint8_t *>(texture->data);
+		uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);
+		const size_t in_row = wb * bs, out_row = tiled ? wb * 16u * px : 4u * width * px;		// bytes per block row
+		auto row_of = [&](int b) { return hb * (size_t)b / (size_t)B; };
+		std::atomic<int> uploaded{ 1 };			// bands whose upload has been issued and whose event is recorded (-1: the uploader failed)
+		hipError_t up_error = hipSuccess;
+		const int device = c.device;
+		// (band 0 goes up from THIS thread, on the main stream, while the helper -- whose first HIP call costs a few hundred microseconds -- starts)
+		std::thread uploader([&, device]() {
+			hipError_t e = hipSetDevice(device);
+			for (int b = 1; b < B && e == hipSuccess; b++) {
+				const size_t r0 = row_of(b), r1 = row_of(b + 1);
+				e = hipMemcpyAsync(d_in + r0 * in_row, src + r0 * in_row, (r1 - r0) * in_row, hipMemcpyHostToDevice, c.stream_up);
+				if (e == hipSuccess) e = hipEventRecord(c.ev_up[b], c.stream_up);
+				if (e == hipSuccess) uploaded.store(b + 1, std::memory_order_release);
+			}
+			if (e != hipSuccess) { up_error = e; uploaded.store(-1, std::memory_order_release); }
+		});
+		// band b's decode: behind its upload (band 0's went up on this stream; the others' events), one call of the device entry
+		auto launch_band = [&](int b) -> bool {
+			int seen;
+			while ((seen = uploaded.load(std::memory_order_acquire)) >= 0 && seen <= b) std::this_thread::yield();
+			if (seen < 0) return false;
+			const size_t r0 = row_of(b), r1 = row_of(b + 1);
+			if (b > 0 && !try_hip(hipStreamWaitEvent(c.stream, c.ev_up[b], 0), "hipStreamWaitEvent")) return false;
+			const int rc = tiled ? detexhipDecompressTextureTiledDevice(texture->format, d_in + r0 * in_row, (int)wb, (int)(r1 - r0), d_out + r0 * out_row, pixel_format, c.stream, d_status)
+				: detexhipDecompressTextureLinearDevice(texture->format, d_in + r0 * in_row, (int)width, (int)(4u * (r1 - r0)), (int)wb, (int)(r1 - r0), d_out + r0 * out_row,
+					width * px, pixel_format, c.stream, d_status);
+			return rc == 0;
+		};
+		// Band b + 1 is launched BEFORE band b's download is asked for: the download call blocks this thread until the copy is done, and a launch
+		// issued only then leaves the link idle for a launch latency per band (8 x ~30 us of a 5 ms call).  Same stream, so the download of band b
+		// runs behind the decode of band b + 1 -- which it does not need, and which takes microseconds.
+		bool fine = try_hip(hipMemcpyAsync(d_in, src, row_of(1) * in_row, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)") && launch_band(0);
+		for (int b = 0; b < B && fine; b++) {
+			if (b + 1 < B) fine = launch_band(b + 1);
+			const size_t r0 = row_of(b), r1 = row_of(b + 1);
+			fine = fine && try_hip(hipMemcpyAsync(pixel_buffer + r0 * out_row, d_out + r0 * out_row, (r1 - r0) * out_row, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
+		}
+		uploader.join();
+		if (uploaded.load(std::memory_order_acquire) < 0) { detexSetErrorMessage("libdetexhip: hipMemcpyAsync(H2D) failed: %s", hipGetErrorString(up_error)); fine = false; }
+		if (!fine || injected_failure()) return kFalse;
+		if (!pinned_status && !try_hip(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
+		if (!try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
+		if (*h_status == 0) { c.dirty = false; return kTrue; }
+		if (!pinned_status) {
+			if (!try_hip(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync") || !try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
+		}
+		c.dirty = false;
+		return block_failed();
+	}
+
 	Outcome via_staging() const {
 		const bool pinned_in = in_bytes <= Tune::kHostPinnedInputBytes;
 		DirectExchange x;
@@ -627,6 +715,7 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	Outcome r = call.via_resident_service();
 	if (r == kNotTaken) r = call.via_owned_pixel_buffer();
 	if (r == kNotTaken) r = call.via_pinned_exchange();
+	if (r == kNotTaken) r = call.via_staging_duplex();
 	if (r == kNotTaken) r = call.via_staging();
 	return r == kTrue;
 }

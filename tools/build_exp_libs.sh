@@ -17,6 +17,7 @@
 #   prioN / bc6prioN        s_setprio staging policy N of BC7 / BC6H (dev_common.h: stage_priority)
 #   sgprconst               v_bitop3 masks left in SGPRs
 #   rgtc1gN                 RGTC1 blocks per lane
+#   hostduplexN             host tier: textures with at least N bytes of pixels upload and download at the same time (0 = never)
 #   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
 #   loadpolicyN             decode_linear: cache policy of the block load (bit 0 sc0, bit 1 sc1, bit 2 nt)
@@ -58,6 +59,7 @@ for v in "$@"; do
       bc6prio*) body+="static constexpr int kBc6hPrio = ${k#bc6prio}; " ;;
       sgprconst) body+="static constexpr bool kMasksInVgprs = false; " ;;
       rgtc1g*) body+="static constexpr int kRgtc1LaneBlocks = ${k#rgtc1g}; " ;;
+      hostduplex*) body+="static constexpr unsigned long kHostDuplexBytes = ${k#hostduplex}; " ;;
       hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
       loadpolicy*) body+="static constexpr int kLoadPolicy = ${k#loadpolicy}; " ;;
