@@ -556,8 +556,9 @@ struct TextureCall {
 	// texture of its own to the device entry); the status word is shared by the bands' launches and read once at the end.
 	Outcome via_staging_duplex() const {
 		constexpr int B = Tune::kHostDuplexBands;
-		// (worth it from about 16 MiB of blocks on -- 0.3 ms of upload to hide: BC1 4096^2, 8 MiB, loses 0.2 ms to the helper thread and the eight bands)
-		if (Tune::kHostDuplexBytes == 0 || out_bytes < Tune::kHostDuplexBytes || in_bytes < Tune::kHostDuplexBytes / 2 || hb < (size_t)(2 * B)) return kNotTaken;
+		// (worth it from 32 MiB of blocks on -- 0.6 ms of upload to hide, of which the helper thread and the eight bands cost ~0.3: BC1 4096^2,
+		// 8 MiB of blocks, loses 0.2 ms, BC7 4096^2, 16 MiB, 0.08; BC1 8192^2, 32 MiB, gains 0.18, 64 MiB 0.5-0.55)
+		if (Tune::kHostDuplexBytes == 0 || out_bytes < Tune::kHostDuplexBytes || in_bytes < Tune::kHostDuplexBytes || hb < (size_t)(2 * B)) return kNotTaken;
 		if (!tiled && !(width == 4u * wb && height == 4u * hb)) return kNotTaken;
 		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
 		if (!c.stream_up) {
@@ -568,7 +569,9 @@ struct TextureCall {
 		DirectExchange x;
 		if (!direct_exchange(c, 0, 0, &x)) return kFalse;
 		if (!reserve(&c.d_out, &c.out_cap, out_bytes) || !reserve(&c.d_in, &c.in_cap, in_bytes)) return kFalse;
-		const bool pinned_status = wb * hb <= ((size_t)1 << 20);
+		// (the status word stays in device memory here -- a call of this size does not notice the 13 us that fetching it costs, and a texture full of
+		// invalid blocks would pay a trip across the link per wave for a word in pinned memory: see via_staging)
+		const bool pinned_status = false;
 		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);
 		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
 		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
@@ -640,10 +643,12 @@ struct TextureCall {
 			if (!try_hip(hipMemcpyAsync(c.d_in, texture->data, in_bytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)")) return kFalse;
 			d_in = static_cast<const uint8_t *>(c.d_in);
 		}
-		// The status word: up to 2^20 blocks it lives in the pinned header itself -- only a wave that holds a failed block touches it (one
-		// load, at most one store across the link), and the call saves the copy that would fetch it (13 us); beyond that (tens of thousands
-		// of waves may hold a failed block of a random stream) it stays in device memory and is fetched into the pinned word.
-		const bool pinned_status = wb * hb <= ((size_t)1 << 20);
+		// The status word: up to 2^18 blocks (2048^2) it lives in the pinned header itself -- only a wave that holds a failed block touches it (one
+		// load, at most one store across the link), and the call saves the copy that would fetch it (13 us of a call of at most 0.4 ms); beyond
+		// that it stays in device memory and is fetched into the pinned word: every wave of a texture FULL of invalid blocks makes that trip across
+		// the link (random BC6H, an eighth of whose blocks are reserved modes: 4096^2, 16384 waves, 5.6 ms instead of 2.6 with the word in pinned
+		// memory -- round 6, when the limit was still 2^20 blocks).
+		const bool pinned_status = wb * hb <= ((size_t)1 << 18);
 		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
 		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
 		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;

@@ -78,7 +78,7 @@ struct ProductTune {
 	static constexpr unsigned long kHostPinnedInputBytes = 1024u << 10;
 	// ... and a pixel buffer the library handed out (detexhipAllocPixelBuffer) is written by the kernel directly up to this many bytes of pixels
 	static constexpr unsigned long kOwnedDirectBytes = 8ul << 20;
-	// ... and textures with at least this many bytes of pixels go up and come down AT THE SAME TIME: bands of block rows, band k + 1 uploaded by a
+	// ... and textures with at least this many bytes of blocks AND of pixels go up and come down AT THE SAME TIME: bands of block rows, band k + 1 uploaded by a
 	// helper thread while band k is decoded and downloaded (the link is full duplex; copies between pageable memory and the device block their
 	// calling thread, hence the second thread: host_tier.cpp: via_staging_duplex); 0 = never
 	static constexpr unsigned long kHostDuplexBytes = 32ul << 20;

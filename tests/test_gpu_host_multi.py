@@ -23,10 +23,11 @@ def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda()
 
 
-@pytest.mark.parametrize("name,W,H", [("BC1", 8192, 4096), ("BPTC_FLOAT", 4096, 2048), ("RGTC1", 16384, 8192), ("BPTC", 4096, 4100), ("ETC2", 2050, 9000)])
+@pytest.mark.parametrize("name,W,H", [("BC1", 8192, 8192), ("BPTC_FLOAT", 4096, 2048), ("RGTC1", 16384, 8192), ("BPTC", 4096, 4100), ("BPTC", 8192, 4100), ("ETC2", 2050, 9000)])
 def test_host_tier_large_textures_match_device_tier(name, W, H, torch_cuda, hiplib):
-    """large textures (64-256 MiB of pixels), incl. clipped geometry: the host-pointer drop-in
-    entry == the device tier on the same stream, byte for byte, and the bool result agrees"""
+    """large textures (64-256 MiB of pixels), incl. clipped geometry, on both sides of the duplex path's limit (32 MiB of blocks: BC1 8192^2, RGTC1
+    16384 x 8192, BPTC 8192 x 4100 -- 1025 block rows in eight bands -- go up beside their download): the host-pointer drop-in entry == the device
+    tier on the same stream, byte for byte, and the bool result agrees"""
     from detex_amd import binding
     torch = torch_cuda
     fmt = F.BY_NAME[name]
@@ -311,12 +312,12 @@ def test_gather_across_devices_all_three_branches():
     print("peer_access per case:", [(c["name"], c["pad"], c["gather"], c["peer_access"]) for c in res["cases"]])
 
 
-@pytest.mark.parametrize("W,H", [(1024, 1024), (4100, 4096), (512, 512), (4096, 4096), (4096, 4100)])
+@pytest.mark.parametrize("W,H", [(1024, 1024), (4100, 4096), (512, 512), (8192, 4100), (2048, 2048), (2048, 2052)])
 def test_host_tier_status_does_not_leak_between_calls(W, H, hiplib, oracle):
     """a texture with invalid blocks (result false) followed by a valid one of the same size (result true) and again an invalid one, on
     the pinned-exchange path (512^2), the staged path with its status word in pinned memory (1024^2) and with the device word that is
-    kept zero between calls (> 2^20 blocks), and the duplex staged path (64 MiB of pixels in whole blocks: uploads beside downloads, eight
-    bands sharing the status word) with either kind of word (4096^2: 2^20 blocks; 4096 x 4100): the status of one call never shows in the next"""
+    kept zero between calls (> 2^18 blocks: both sides of that limit, 2048^2 and 2048 x 2052), and the duplex staged path (8192 x 4100: 32 MiB of blocks in
+    whole blocks: uploads beside downloads, eight bands sharing the device word): the status of one call never shows in the next"""
     fmt = F.BY_NAME["BPTC"]
     wb, hb = (W + 3) // 4, (H + 3) // 4
     bad = ol.stream_u(fmt, wb * hb, seed=0x57A7)                 # random BC7: 0.4 % reserved blocks
@@ -585,7 +586,7 @@ def test_free_of_an_owned_buffer_waits_for_the_decode_in_flight(hiplib, oracle):
 
 
 @pytest.mark.parametrize("path,name,W,H", [("leaf", "BPTC", 4, 4), ("pinned", "BPTC", 256, 256), ("banded", "BPTC", 512, 512), ("staged_pinned_status", "BPTC", 1024, 1024),
-                                           ("staged_device_status", "BPTC", 4100, 4096), ("staged_duplex", "BPTC", 4096, 4100), ("owned", "BPTC", 1024, 1024), ("tiled_pinned", "BPTC", 256, 256),
+                                           ("staged_device_status", "BPTC", 4100, 4096), ("staged_duplex", "BPTC", 8192, 4100), ("owned", "BPTC", 1024, 1024), ("tiled_pinned", "BPTC", 256, 256),
                                            ("blocks_direct", "BPTC", 0, 0), ("blocks_staged", "BPTC", 0, 0), ("histogram", "BPTC", 0, 0)])
 def test_call_after_a_failure_behind_the_launch_starts_clean(path, name, W, H, hiplib, oracle):
     """detexhipTestFailAfterLaunch(1): the next call returns false right behind its kernel launch -- with invalid blocks in its input, so the
