@@ -73,6 +73,9 @@ for i in 1 2 3 4 5 6 7 8 9 10; do tests/c_client/detex_client --oneshot-breakdow
 f=$(find $OUT/oneshot/trace -name "*hip_api_stats.csv" | head -1); [ -n "$f" ] && head -12 $f | tee $OUT/oneshot/oneshot_hip_api_stats.csv | head -6
 f=$(find $OUT/oneshot/trace -name "*hip_api_trace.csv" | head -1); [ -n "$f" ] && grep -v "__hipRegister" $f > $OUT/oneshot/oneshot_hip_api_trace.csv
 rm -rf $OUT/oneshot/trace $OUT/oneshot/trace.log
+echo "== round 6 (second session): who wrote the blocks (upload / device copy before each launch); large textures through the host-pointer entry (duplex staged path)"
+python tools/gpu_fresh_blocks.py BC1,BC3,BPTC_FLOAT 8192 80 2>/dev/null > $OUT/fresh_blocks.jsonl; python tools/gpu_fresh_blocks.py BC1 16384 40 2>/dev/null >> $OUT/fresh_blocks.jsonl; wc -l $OUT/fresh_blocks.jsonl
+python tools/gpu_host_big.py $ROOT/detex_amd/lib/libdetexhip.so 2>/dev/null > $OUT/host_big.jsonl; cut -c1-200 $OUT/host_big.jsonl | head -3
 echo "== mode histograms / mip chains"; (timeout 300 python tools/bench_histogram.py 2>/dev/null) | tee $OUT/histogram.txt | cut -c1-120; timeout 300 python tools/bench_mips.py 2>/dev/null | tail -1 > $OUT/mips.json; cut -c1-200 $OUT/mips.json
 if ! skip fuzz; then echo "== fuzz 150 s"; timeout 400 python tools/gpu_fuzz.py 150 50000 2>&1 | tail -1 | tee $OUT/fuzz.log; fi
 rm -rf $OUT/pmc_*_*_*_* $OUT/pmc_*_*_* 2>/dev/null
