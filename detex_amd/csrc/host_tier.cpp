@@ -563,18 +563,24 @@ struct TextureCall {
 		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
 		if (!c.stream_up) {
 			if (!try_hip(hipStreamCreateWithFlags(&c.stream_up, hipStreamNonBlocking), "hipStreamCreate")) { c.stream_up = nullptr; return kFalse; }
+			bool all = true;
 			for (hipEvent_t &e : c.ev_up)
-				if (!try_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) { e = nullptr; return kFalse; }
+				if (all && !try_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) { e = nullptr; all = false; }
+			if (!all) {		// (all or nothing: the next call starts over)
+				for (hipEvent_t &e : c.ev_up) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+				(void)hipStreamDestroy(c.stream_up);
+				c.stream_up = nullptr;
+				return kFalse;
+			}
 		}
 		DirectExchange x;
 		if (!direct_exchange(c, 0, 0, &x)) return kFalse;
 		if (!reserve(&c.d_out, &c.out_cap, out_bytes) || !reserve(&c.d_in, &c.in_cap, in_bytes)) return kFalse;
-		// (the status word stays in device memory here -- a call of this size does not notice the 13 us that fetching it costs, and a texture full of
-		// invalid blocks would pay a trip across the link per wave for a word in pinned memory: see via_staging)
-		const bool pinned_status = false;
+		// (the status word stays in device memory here and is fetched into the pinned header at the end: a call of this size does not notice the 13 us,
+		// and a texture full of invalid blocks would pay a trip across the link per wave for a word in pinned memory -- see via_staging)
 		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);
-		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
-		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
+		uint32_t *d_status = c.d_status + kStagedStatusWord;
+		*h_status = 0xFFFFFFFFu;
 		c.dirty = true;
 		const uint8_t *src = static_cast<const uint8_t *>(texture->data);
 		uint8_t *d_in = static_cast<uint8_t *>(c.d_in), *d_out = static_cast<uint8_t *>(c.d_out);
@@ -624,12 +630,11 @@ struct TextureCall {
 		uploader.join();
 		if (uploaded.load(std::memory_order_acquire) < 0) { detexSetErrorMessage("libdetexhip: hipMemcpyAsync(H2D) failed: %s", hipGetErrorString(up_error)); fine = false; }
 		if (!fine || injected_failure()) return kFalse;
-		if (!pinned_status && !try_hip(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
+		if (!try_hip(hipMemcpyAsync(const_cast<uint32_t *>(h_status), d_status, 4, hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)")) return kFalse;
 		if (!try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
 		if (*h_status == 0) { c.dirty = false; return kTrue; }
-		if (!pinned_status) {
-			if (!try_hip(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync") || !try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
-		}
+		// (the device word is zero between calls: restore that before reporting)
+		if (!try_hip(hipMemsetAsync(d_status, 0, 4, c.stream), "hipMemsetAsync") || !try_hip(hipStreamSynchronize(c.stream), "hipStreamSynchronize")) return kFalse;
 		c.dirty = false;
 		return block_failed();
 	}
