@@ -1098,7 +1098,8 @@ class Bench:
             self.add_collective_keys(result)
         result.update(self.extras)
         if not multi:
-            self.add_host_tier(result)
+            if not args.no_host_tier:
+                self.add_host_tier(result)
             if not args.no_extras and not args.formats_json:
                 self.add_per_format(result)
                 self.add_whole_images(result)
@@ -1131,6 +1132,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-settle", action="store_true", help="start the contract's W + K launches cold (no settling launches before them)")
     ap.add_argument("--no-extras", action="store_true", help="skip per_format / strong_image_32768 / weak / gather extras")
+    ap.add_argument("--no-host-tier", action="store_true", help="skip the host-pointer row (tools/gpu_kernel_stats.sh: its banded calls launch the headline's kernel on eighths of the image)")
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is timed by default when N > 1)")
     ap.add_argument("--formats-json", default=None, help="also bench every format (U, M, C streams), write a table to this path")
     args = ap.parse_args()

@@ -244,6 +244,42 @@ def test_multi_device_entries_from_concurrent_threads(torch_cuda, oracle):
     assert not errors, errors
 
 
+def test_duplex_staged_path_from_concurrent_threads(torch_cuda, hiplib):
+    """three threads, each decoding its own large texture (RGTC2 8192 x 4100 / 8192 x 4104 / 8192 x 4108: 32+ MiB of blocks, so the upload runs beside
+    the download on a helper thread and a second stream per calling thread) twice at the same time: every thread gets its own pixels, equal
+    to the device tier's on the same blocks"""
+    import threading
+    from detex_amd import binding
+    torch = torch_cuda
+    fmt = F.BY_NAME["RGTC2"]
+    cases = []
+    for t in range(3):
+        W, H = 8192, 4100 + 4 * t
+        data = ol.stream_u(fmt, (W // 4) * (H // 4), seed=0xD0B1 + t)
+        want = binding.decompress_linear_device(fmt, _dev(torch, data), W, H).cpu().numpy()
+        cases.append((W, H, data, want))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(t):
+        try:
+            W, H, data, want = cases[t]
+            for _ in range(2):
+                ok, got = hiplib.linear(fmt, data, W, H)
+                if not ok or not np.array_equal(got, want):
+                    errors.append(("pixels differ", t))
+            hiplib.lib.detexhipReleaseThreadResources.restype = None
+            hiplib.lib.detexhipReleaseThreadResources()
+        except Exception as e:  # noqa
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 # ---- the gather's three copy branches (multi_device.cpp: flat peer copy, 2-D copy over a peer mapping, row-wise copies without one) ----------
 _GATHER_WORKER = r'''
 import json, sys

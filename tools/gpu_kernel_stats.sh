@@ -3,7 +3,7 @@
 # 8192^2 BC1 launch and nothing else) and the driver's exact command (every kernel of the extras under its full name).
 export TMPDIR=/tmp
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/kernel_stats; rm -rf $OUT; mkdir -p $OUT
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/headline -o k --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-extras > $OUT/headline_bench.json 2> $OUT/headline.log
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/headline -o k --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-extras --no-host-tier > $OUT/headline_bench.json 2> $OUT/headline.log
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/driver -o k --output-format csv -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_bench.json 2> $OUT/driver.log
 cd $ROOT
 for t in headline driver; do f=$(find $OUT/$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${t}_kernel_stats.csv; rm -rf $OUT/$t; done
