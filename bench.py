@@ -293,7 +293,7 @@ class RotatingInputs:
     def __init__(self, job):
         self.job = job
         n = int(job.d_blocks.numel())
-        self.inputs = [job.d_blocks] + [torch.roll(job.d_blocks, 4096 * k) for k in range(1, max(3, -(-(640 << 20) // n)))]
+        self.inputs = [job.d_blocks] + [torch.roll(job.d_blocks, 4096 * k) for k in range(1, min(32, max(3, -(-(640 << 20) // n))))]    # (at most 32: tiny plumbing images)
         self.k = 0
         self.blocks, self.alg_bytes, self.tpx, self.W, self.H = job.blocks, job.alg_bytes, job.tpx, job.W, job.H
 
@@ -689,6 +689,23 @@ class Bench:
         if strong:
             extras["gather"] = self.time_gathers(fmt, strong, shard, job.d_out)
             extras["gather"]["decode_ms_per_step"] = round(wall / args.steps * 1e3, 4)
+        # (a'') the same band decode with its blocks coming out of HBM: from N = 2 on a band's blocks (<= 256 MiB) fit the Infinity Cache and the timed
+        # loop above re-reads them from there, which the whole image on one GPU (512 MiB of blocks) cannot -- a strong-scaling curve taken from `value`
+        # alone would be super-linear for that reason.  Here every rank decodes R different inputs of its band's shape in turn (same barriers, max over ranks).
+        if strong:
+            try:
+                rot = RotatingInputs(job)
+                r_wall, r_ms = self.timed(rot, args.steps, args.warmup)
+                extras["blocks_from_hbm"] = {"value_gpixel_s": round(strong * strong * args.steps / r_wall / 1e9, 3), "ms_per_step": round(r_wall / args.steps * 1e3, 5),
+                                             "launch_us": round(r_ms * 1e3, 3), "inputs_per_rank": len(rot.inputs),
+                                             "note": "the headline's loop over R different inputs per rank in turn (every launch's blocks out of HBM): the figure to divide "
+                                                     "by the N = 1 line's strong_image_32768 for a like-for-like strong-scaling curve (DESIGN.md sections 4 and 7)"}
+                del rot
+                job.step()                              # (the band's own pixels back in d_out)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa
+                extras["blocks_from_hbm"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         # (a') BASELINE configs[4]: BC6H -> FLOAT_RGBX16 ("FP16 RGBA"), 32768^2 sharded over the ranks, decode-only and gather separately
         if strong and fmt.name != "BPTC_FLOAT":
             try:

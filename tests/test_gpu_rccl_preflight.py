@@ -68,6 +68,8 @@ def test_bench_multi_gpu_branch_under_rccl_world_size_1():
     assert b6["whole_band_digests_match_reference_all_ranks"] is True and b6["verified_bit_exact_rows_min_over_ranks"] > 0
     assert "error" not in b6["gather"]["to_root"] and "error" not in b6["gather"]["to_all"]
     assert d["weak"]["value_gpixel_s"] > 0
+    hbm = d["blocks_from_hbm"]                                       # the headline's loop over different inputs per rank (like-for-like with the N = 1 whole image)
+    assert "error" not in hbm and hbm["value_gpixel_s"] > 0 and hbm["inputs_per_rank"] >= 3, hbm
     print("bench.py N>1 branch under RCCL %s: value %.1f Gpixel/s, BC6H 32768^2 %.1f Gpixel/s" % (d.get("rccl_version"), d["value"], b6["value_gpixel_s"]))
 
 
