@@ -64,24 +64,7 @@ DH Codes48 codes48_from_le(uint32_t w0, uint32_t w1) {	// w0,w1 = first 8 bytes 
 	return c;
 }
 
-// The row-split form of the two BC1 decoders (kernels.h: decode_linear_rowsplit): `row_setup` is everything the block's sixteen texels
-// share -- the palette and the selector word, five dwords -- and `row_texels` picks texel row `row` (wave-uniform) from them.
-template <bool PUNCHTHROUGH> struct S3tcRowSplit {
-	static constexpr int kSharedDwords = 5;
-	static DH void row_setup(uint2 blk, uint32_t (&s)[5]) {
-		uint32_t p[4];
-		s3tc_palette(blk.x, (blk.x & 0xFFFFu) > (blk.x >> 16), PUNCHTHROUGH ? 0u : 0xFF000000u, p);
-		s[0] = p[0]; s[1] = p[1]; s[2] = p[2]; s[3] = p[3]; s[4] = blk.y;
-	}
-	static DH void row_texels(const uint32_t (&s)[5], uint32_t row, uint32_t (&o)[4]) {
-		const uint32_t idx = s[4] >> (8u * row);
-#pragma unroll
-		for (int k = 0; k < 4; k++) o[k] = select4(bit_to_mask(idx, 2 * k), bit_to_mask(idx, 2 * k + 1), s[0], s[1], s[2], s[3]);
-	}
-};
-
 struct DecBC1 {
-	using RowSplit = S3tcRowSplit<false>;
 	static constexpr int kBlockBytes = 8, kPixelBytes = 4;
 	// decompress-bc.c:23-61
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t, uint32_t (&d)[16]) {
@@ -93,7 +76,6 @@ struct DecBC1 {
 };
 
 struct DecBC1A {
-	using RowSplit = S3tcRowSplit<true>;
 	static constexpr int kBlockBytes = 8, kPixelBytes = 4;
 	// decompress-bc.c:87-132
 	template <bool CHECKED> static DH bool decode(uint2 blk, uint32_t, uint32_t flags, uint32_t (&d)[16]) {

@@ -111,8 +111,6 @@ DH uint32_t extract32(const Bits128 &b, uint32_t pos) {
 template <class D> DH auto call_prepare(int) -> decltype(D::prepare(), void()) { D::prepare(); }
 template <class D> DH void call_prepare(long) {}
 template <class D> DH void prepare_tables() { call_prepare<D>(0); }
-template <class D, class = void> struct HasTables { static constexpr bool value = false; };
-template <class D> struct HasTables<D, decltype(D::prepare(), void())> { static constexpr bool value = true; };
 
 // ---- per-lane private rows in LDS ------------------------------------------------------------
 // ROWS values of T owned by each lane of a 256-thread workgroup, laid out [row][lane] so that any

@@ -113,27 +113,6 @@ template <class Dec, int EPI> hipError_t launch_linear_epi(const Geometry &g) {
 				return hipGetLastError();
 			}
 		}
-		if constexpr (Tune::kRowSplit && HasRowSplit<Dec>::value && EPI == kEpiNone) {	// MEASUREMENT BUILDS ONLY: cooperative row split
-			constexpr auto kernel = &decode_linear_rowsplit<Dec>;
-			hipLaunchKernelGGL(kernel, dim3((n + 63u) / 64u), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch);
-			return hipGetLastError();
-		}
-		if constexpr (kRow == 4 && Tune::kOneWaveGroups && !HasTables<Dec>::value && EPI == kEpiNone) {	// MEASUREMENT BUILDS ONLY
-			hipLaunchKernelGGL((decode_linear_onewave<Dec, EPI>), dim3((n + 63u) / 64u), dim3(64), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
-			return hipGetLastError();
-		}
-		if constexpr (kRow == 4 && Tune::kRowWave) {		// MEASUREMENT BUILDS ONLY: wave w of a 64-block workgroup stores texel row w
-			constexpr auto kernel = &decode_linear_rowwave<Dec, EPI>;
-			hipLaunchKernelGGL(kernel, dim3((n + 63u) / 64u), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n,
-				g.pitch, g.status, g.decode_flags);
-			return hipGetLastError();
-		}
-		if constexpr (kRow == 8 && Tune::kWideTilesPerGroup > 1) {		// MEASUREMENT BUILDS ONLY: several tiles per workgroup, blocks requested up front
-			constexpr auto kernel = &decode_linear_wide_tiles<Dec, EPI, Tune::kWideTilesPerGroup>;
-			hipLaunchKernelGGL(kernel, dim3((tiles + Tune::kWideTilesPerGroup - 1u) / Tune::kWideTilesPerGroup), dim3(256),
-				occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
-			return hipGetLastError();
-		}
 		// non-temporal row stores (43 vs 51 us with cached stores on BC1 8192^2)
 		constexpr auto kernel = &decode_linear<Dec, EPI, true>;
 		hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), occupancy_cap_lds<kernel>(workgroups_per_cu(g.resident)), g.stream, g.blocks, px, g.wb, n, g.pitch,

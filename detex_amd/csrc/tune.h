@@ -44,19 +44,6 @@ struct ProductTune {
 	// decode_linear: the block requested BEFORE the format tables are copied into LDS (and waited for behind that copy's barrier) instead of
 	// after it (measurement builds; the product loads after the barrier: profiles/AB_RECORD.md rounds 2 and 6)
 	static constexpr bool kLoadBeforeTables = false;
-	// 64-bit pixels, linear layout: tiles (of 256 blocks) per workgroup, all of the workgroup's blocks requested before the table copy and the
-	// tiles then decoded and stored one after the other -- a software pipeline for blocks that come out of HBM (1 = the product's one tile per
-	// workgroup; measurement builds: profiles/AB_RECORD.md round 6)
-	static constexpr int kWideTilesPerGroup = 1;
-	// 32-bit pixels, linear layout: a workgroup covers 64 blocks and wave w decodes and stores TEXEL ROW w of them -- one store per lane, every
-	// block decoded by four lanes (kernels.h: decode_linear_rowwave); measurement builds: profiles/AB_RECORD.md round 6
-	static constexpr bool kRowWave = false;
-	// ... and the cooperative form of that for the decoders that define Dec::RowSplit (BC1 / BC1A): wave 0 decodes what the block's texels share
-	// into LDS, then wave w picks and stores texel row w (kernels.h: decode_linear_rowsplit)
-	static constexpr bool kRowSplit = false;
-	static constexpr int kRowSplitPrefetch = 0;	// ... wave 1 also requests (and drops) the blocks of the workgroup this many workgroups further on
-	// decode_linear with ONE-WAVE workgroups (64 blocks, 4 KiB of 32-bit pixels per workgroup) for the decoders without format tables
-	static constexpr bool kOneWaveGroups = false;
 	// decode_linear: cache policy of the block load (bits as for the stores; 0 = the compiler's plain load)
 	static constexpr int kLoadPolicy = 0;
 	// s_sleep argument between a wave's row stores (0 = none): does a smoother store issue raise the write rate? (profiles/AB_RECORD.md)

@@ -97,9 +97,12 @@ def test_bc1_tile4x4_variant_matches(binding, torch_cuda, oracle):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC", 5), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3), ("BC1", 2), ("BPTC_FLOAT", 2)])
+@pytest.mark.parametrize("name,variant", [("BPTC", 3), ("BPTC", 4), ("BPTC", 5), ("BPTC_FLOAT", 3), ("BPTC_SIGNED_FLOAT", 3), ("BC1", 2), ("BPTC_FLOAT", 2),
+                                          ("BC1", 8), ("BC3", 8), ("ETC2", 8), ("BPTC", 8), ("EAC_RG11", 8), ("BC1", 9), ("BC1A", 9), ("BC1", 10), ("BC3", 10),
+                                          ("BPTC_FLOAT", 11), ("BPTC_SIGNED_FLOAT", 11)])
 def test_alternative_decoder_variants_match(name, variant, binding, torch_cuda, oracle, forced_vectors):
-    """the A/B decoder implementations (profiles/AB_RECORD.md) decode identically, forced classes included"""
+    """the A/B decoder implementations and kernel shapes (profiles/AB_RECORD.md; 8-11: the store-shape kernels of round 6, tools/ab/kernels_store_shape.h)
+    decode identically, forced classes included"""
     torch = torch_cuda
     fmt = F.BY_NAME[name]
     W, H = 2048, 512

@@ -7,6 +7,10 @@
 //   5  BPTC with mode-sorted waves (workgroup counting sort by mode)
 //   6  persistent grid, twice as many workgroups as are resident at once (kernels_persistent.h)      [32-bit pixels]
 //   7  persistent grid, exactly the resident count
+//   8  wave w of a 64-block workgroup decodes and stores texel row w: one store per lane, every block decoded four times (kernels_store_shape.h)   [32-bit pixels]
+//   9  ... the cooperative form: wave 0 decodes palettes into LDS, wave w picks and stores row w                                                    [BC1 / BC1A]
+//  10  one-wave workgroups (64 blocks, four stores per lane)                                                    [32-bit pixels, decoders without tables]
+//  11  two tiles per workgroup, both blocks requested before the table copy                                                              [64-bit pixels]
 // Included by the tools/ab/formats_*_ab.hip translation units AFTER the product's launchers.h; the per-decoder hooks are ab_traits.h's
 // templates, specialised by the translation unit that owns the decoder.  The product sources know nothing of this directory: an A/B
 // translation unit includes the product headers, re-points FMT()'s linear launcher at ab_linear<> below and then includes the product's
@@ -15,6 +19,7 @@
 #include "launchers.h"
 #include "ab_traits.h"
 #include "kernels_persistent.h"
+#include "kernels_store_shape.h"
 
 namespace detexhip {
 
@@ -72,6 +77,35 @@ template <class Dec, int EPI> bool ab_launch_linear(const Geometry &g, hipError_
 			return true;
 		}
 	}
+	if constexpr (EpilogueOf<Dec, EPI>::kRowDwords == 4) {
+		if (g.variant == 8) {
+			hipLaunchKernelGGL((decode_linear_rowwave<Dec, EPI>), dim3((n + 63u) / 64u), block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
+			*result = hipGetLastError();
+			return true;
+		}
+		if constexpr (RowSplitOf<Dec>::kAvailable && EPI == kEpiNone) {
+			if (g.variant == 9) {
+				hipLaunchKernelGGL((decode_linear_rowsplit<Dec>), dim3((n + 63u) / 64u), block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch);
+				*result = hipGetLastError();
+				return true;
+			}
+		}
+		if constexpr (!HasTables<Dec>::value && EPI == kEpiNone) {
+			if (g.variant == 10) {
+				hipLaunchKernelGGL((decode_linear_onewave<Dec, EPI>), dim3((n + 63u) / 64u), dim3(64), 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
+				*result = hipGetLastError();
+				return true;
+			}
+		}
+	}
+	if constexpr (EpilogueOf<Dec, EPI>::kRowDwords == 8) {
+		if (g.variant == 11) {
+			const uint32_t tiles = (n + 255u) / 256u;
+			hipLaunchKernelGGL((decode_linear_wide_tiles<Dec, EPI, 2>), dim3((tiles + 1u) / 2u), block, 0, g.stream, g.blocks, px, g.wb, n, g.pitch, g.status, g.decode_flags);
+			*result = hipGetLastError();
+			return true;
+		}
+	}
 	return false;
 }
 
@@ -92,7 +126,7 @@ template <class Dec> hipError_t ab_linear(const Geometry &g) {
 	}
 	return launch_linear<Dec>(g);
 }
-static const int g_raise_variant_limit = (g_max_variant = 7);
+static const int g_raise_variant_limit = (g_max_variant = 11);
 
 }  // namespace detexhip
 

@@ -23,10 +23,6 @@
 #   loadpolicyN             decode_linear: cache policy of the block load (bit 0 sc0, bit 1 sc1, bit 2 nt)
 #   loadfirst               decode_linear: the block requested before the table copy's barrier
 #   prefetchN               decode_linear: each wave also requests (and drops) the blocks N tiles further on
-#   rowsplit                BC1 / BC1A, linear layout, native target: wave 0 of a 64-block workgroup decodes the palettes into LDS, wave w picks and stores texel row w
-#   onewave                 32-bit pixels, decoders without tables, native target: one-wave workgroups (64 blocks each)
-#   rowwave                 32-bit pixels, linear layout: 64-block workgroups, wave w decodes and stores texel row w (one store per lane)
-#   widetilesN              64-bit pixels, linear layout: N tiles per workgroup, all blocks requested before the table copy (product: 1)
 #   wgN                     N resident workgroups per CU for every linear kernel (0 = no cap; default: the per-format table)
 #   sleepN                  s_sleep N between a wave's row stores (linear kernels)
 #   planarN                 ETC2: most planar blocks per wave decoded cooperatively (0 = always in-lane)
@@ -65,11 +61,6 @@ for v in "$@"; do
       loadpolicy*) body+="static constexpr int kLoadPolicy = ${k#loadpolicy}; " ;;
       loadfirst) body+="static constexpr bool kLoadBeforeTables = true; " ;;
       prefetch*) body+="static constexpr int kPrefetchTiles = ${k#prefetch}; " ;;
-      rowsplitpf*) body+="static constexpr bool kRowSplit = true; static constexpr int kRowSplitPrefetch = ${k#rowsplitpf}; " ;;
-      rowsplit) body+="static constexpr bool kRowSplit = true; " ;;
-      onewave) body+="static constexpr bool kOneWaveGroups = true; " ;;
-      rowwave) body+="static constexpr bool kRowWave = true; " ;;
-      widetiles*) body+="static constexpr int kWideTilesPerGroup = ${k#widetiles}; " ;;
       wg*) body+="static constexpr int kWorkgroupsPerCu = ${k#wg}; " ;;
       sleep*) body+="static constexpr int kStoreSleep = ${k#sleep}; " ;;
       planar*) body+="static constexpr int kEtcPlanarShared = ${k#planar}; " ;;
