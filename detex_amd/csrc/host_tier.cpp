@@ -559,6 +559,9 @@ struct TextureCall {
 		// (worth it from 32 MiB of blocks on -- 0.6 ms of upload to hide, of which the helper thread and the eight bands cost ~0.3: BC1 4096^2,
 		// 8 MiB of blocks, loses 0.2 ms, BC7 4096^2, 16 MiB, 0.08; BC1 8192^2, 32 MiB, gains 0.18, 64 MiB 0.5-0.55)
 		if (Tune::kHostDuplexBytes == 0 || out_bytes < Tune::kHostDuplexBytes || in_bytes < Tune::kHostDuplexBytes || hb < (size_t)(2 * B)) return kNotTaken;
+		// (DETEXHIP_HOST_DUPLEX=0 in the environment: never -- for hosts that do not want a library to start threads; read once per process)
+		static const bool allowed = []() { const char *e = getenv("DETEXHIP_HOST_DUPLEX"); return !(e && *e == '0'); }();
+		if (!allowed) return kNotTaken;
 		if (!tiled && !(width == 4u * wb && height == 4u * hb)) return kNotTaken;
 		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
 		if (!c.stream_up) {

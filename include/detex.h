@@ -159,7 +159,10 @@ DETEXHIP_DECLARE_BLOCK_FN(EAC_SIGNED_RG11)	/* decompress-eac.c:217 */
  * one- and two-component and half-float formats, FLOAT_BGRX16 for BPTC_FLOAT -- for every format the reference
  * itself can convert to them (all but BPTC_SIGNED_FLOAT; the signed 16-bit formats have no path to BGRA8).
  * Any other target is outside the block-decode path: the call returns false with an error message and the
- * texture drivers zero-fill the output. */
+ * texture drivers zero-fill the output.
+ * Threads: re-entrant, per-thread device state (detexhip.h: detexhipReleaseThreadResources).  A texture driver call with at least 32 MiB of
+ * compressed blocks runs ONE helper thread of the library's own for its duration (it uploads the blocks band by band while the calling
+ * thread decodes and downloads: the link is full duplex; DETEXHIP_HOST_DUPLEX=0 in the environment turns that off); nothing of it outlives the call. */
 DETEX_API bool detexDecompressBlock(const uint8_t *bitstring, uint32_t texture_format, uint32_t mode_mask,
 	uint32_t flags, uint8_t *pixel_buffer, uint32_t pixel_format);	/* texture.c:55 */
 DETEX_API bool detexDecompressTextureTiled(const detexTexture *texture, uint8_t *pixel_buffer,

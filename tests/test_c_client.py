@@ -74,15 +74,17 @@ def test_c_client_decodes_the_fixtures_and_a_full_size_stream(built, golden_json
             want = fx[fmt.name]["0x%04X" % F.native_pixel_format(fmt)]
             assert int(got["format"], 16) == fmt.texture_format
             assert got["sha256"] == want["sha256"] and (got["ok"] == "1") == want["ok"], (os.path.basename(exe), fmt.name)
-        for name in ("BC1", "BPTC"):                    # a full-size texture through the host tier: 8192^2, stream U (one with invalid blocks)
+        # a full-size texture through the host tier: 8192^2, stream U (one with invalid blocks) -- with the upload beside the download (32+ MiB of
+        # blocks: the library's helper thread) and, DETEXHIP_HOST_DUPLEX=0, without
+        for name, duplex in (("BC1", "1"), ("BPTC", "1"), ("BPTC", "0")):
             fmt = F.BY_NAME[name]
             seed = ol.STREAM_SEED_BASE + ol.STREAM_SEED_K[name]
             r = subprocess.run([exe, "--stream", "0x%08X" % fmt.texture_format, str(fmt.block_bytes), "0x%X" % seed, "8192", "8192"],
-                               capture_output=True, text=True, env=_clean_env(), timeout=600)
+                               capture_output=True, text=True, env=dict(_clean_env(), DETEXHIP_HOST_DUPLEX=duplex), timeout=600)
             assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
             _, got = _parse(r.stdout.strip().splitlines()[-1])
             want = dg["%s/U" % name]
-            assert got["sha256"] == want["sha256"] and (got["ok"] == "1") == want["ok"], (os.path.basename(exe), name)
+            assert got["sha256"] == want["sha256"] and (got["ok"] == "1") == want["ok"], (os.path.basename(exe), name, duplex)
 
 
 @pytest.mark.gpu
