@@ -157,7 +157,8 @@ DETEXHIP_DECLARE_BLOCK_FN(EAC_SIGNED_RG11)	/* decompress-eac.c:217 */
  * converted inside the decode kernel with the exact result of detexConvertPixels' path (convert.c:885-1063) --
  * BGRA8 / BGRX8 (validate.c:204-209, detex-view.c:182), RGB8 (detex-convert.c:283-284), RGBA8 / RGBX8 for the
  * one- and two-component and half-float formats, FLOAT_BGRX16 for BPTC_FLOAT -- for every format the reference
- * itself can convert to them (all but BPTC_SIGNED_FLOAT; the signed 16-bit formats have no path to BGRA8).
+ * itself can convert to them (all but BPTC_SIGNED_FLOAT; the signed 16-bit formats have no path to BGRA8).  (FLOAT_RGB16 for BPTC_FLOAT
+ * is not among them: the reference's converter for that edge, convert.c:704-718, writes through an uninitialised pointer.)
  * Any other target is outside the block-decode path: the call returns false with an error message and the
  * texture drivers zero-fill the output.
  * Threads: re-entrant, per-thread device state (detexhip.h: detexhipReleaseThreadResources).  A texture driver call with at least 32 MiB of
