@@ -20,6 +20,7 @@
 #   hostduplexN             host tier: textures with at least N bytes of pixels upload and download at the same time (0 = never)
 #   hostdirectN             host tier: byte threshold of the pinned-exchange path (0 = off)
 #   hostpinnedinN           host tier: blocks of up to N bytes reach the staged path's kernel through the pinned buffer (0 = always uploaded)
+#   rabandN                 read-ahead bands of at most N MiB of blocks (product: 128)
 #   loadpolicyN             decode_linear: cache policy of the block load (bit 0 sc0, bit 1 sc1, bit 2 nt)
 #   loadfirst               decode_linear: the block requested before the table copy's barrier
 #   prefetchN               decode_linear: each wave also requests (and drops) the blocks N tiles further on
@@ -58,6 +59,7 @@ for v in "$@"; do
       hostduplex*) body+="static constexpr unsigned long kHostDuplexBytes = ${k#hostduplex}; " ;;
       hostdirect*) body+="static constexpr unsigned long kHostDirectBytes = ${k#hostdirect}; " ;;
       hostpinnedin*) body+="static constexpr unsigned long kHostPinnedInputBytes = ${k#hostpinnedin}; " ;;
+      raband*) body+="static constexpr unsigned long kReadAheadBandBytes = ${k#raband}ul << 20; " ;;
       loadpolicy*) body+="static constexpr int kLoadPolicy = ${k#loadpolicy}; " ;;
       loadfirst) body+="static constexpr bool kLoadBeforeTables = true; " ;;
       prefetch*) body+="static constexpr int kPrefetchTiles = ${k#prefetch}; " ;;
