@@ -38,7 +38,8 @@ for wb, h in ((32768, 8192), (65536, 16384)):
             assert lib.hbmref_fill_image_group(buf.data_ptr(), wb, h, lanes, rotate, seed[0], st) == 0
         return f
     cases += [("four stores per lane, 64-lane workgroups, nt", group(64, 0)), ("four stores per lane, 128-lane workgroups, nt", group(128, 0)),
-              ("four stores per lane, 256 lanes, wave w starts at row w, nt", group(256, 1)), ("four stores per lane, 256 lanes (group kernel), nt", group(256, 0))]
+              ("four stores per lane, 256 lanes, wave w starts at row w, nt", group(256, 1)), ("four stores per lane, 256 lanes (group kernel), nt", group(256, 0)),
+              ("four stores per lane, 512-lane workgroups, nt", group(512, 0)), ("four stores per lane, 1024-lane workgroups, nt", group(1024, 0))]
     def persistent(sync, groups):
         def f():
             seed[0] += 977

@@ -121,6 +121,8 @@ extern "C" __attribute__((visibility("default"))) int hbmref_fill_image_group(vo
 	const dim3 grid((unsigned)(per_row * (height / 4u)));
 	if (lanes == 64) hipLaunchKernelGGL((fill_image_group_kernel<64, false>), grid, dim3(64), 0, s, d, pitch_vectors, per_row, seed);
 	else if (lanes == 128) hipLaunchKernelGGL((fill_image_group_kernel<128, false>), grid, dim3(128), 0, s, d, pitch_vectors, per_row, seed);
+	else if (lanes == 512) hipLaunchKernelGGL((fill_image_group_kernel<512, false>), grid, dim3(512), 0, s, d, pitch_vectors, per_row, seed);
+	else if (lanes == 1024) hipLaunchKernelGGL((fill_image_group_kernel<1024, false>), grid, dim3(1024), 0, s, d, pitch_vectors, per_row, seed);
 	else if (lanes == 256 && rotate) hipLaunchKernelGGL((fill_image_group_kernel<256, true>), grid, dim3(256), 0, s, d, pitch_vectors, per_row, seed);
 	else if (lanes == 256) hipLaunchKernelGGL((fill_image_group_kernel<256, false>), grid, dim3(256), 0, s, d, pitch_vectors, per_row, seed);
 	else return 1;
