@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Does the write rate depend on how a tile's texel rows are dealt out?  Image-layout fills (tools/ubench/hbm_ref.hip): the decode kernels'
 shape (every lane four stores, one per texel row: fill_image) against ONE store per lane -- wave w of the workgroup writes texel row w of 64
-blocks (shape 0), a workgroup writes 4 KiB of one image row (shape 1), two stores per lane (shape 2) -- non-temporal and ordinary stores,
-at the headline's image (32 KiB rows x 8192) and 64 KiB x 16384.  usage: python tools/gpu_store_lanes.py [rounds]      GPU box."""
+blocks (shape 0), a workgroup writes 4 KiB of one image row (shape 1), two stores per lane (shape 2) -- non-temporal and ordinary stores;
+the four-stores shape in 64- / 128- / 512- / 1024-lane workgroups and with the rows rotated per wave; the one-store shape on persistent grids
+(no sync / a barrier / the store acknowledged per tile); four stores each acknowledged before the next -- at the headline's image (32 KiB rows
+x 8192) and 64 KiB x 16384.  usage: python tools/gpu_store_lanes.py [rounds]      GPU box."""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
