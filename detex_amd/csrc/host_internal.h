@@ -17,8 +17,11 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <pthread.h>
+#include <signal.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <utility>
 
 #ifndef DETEXHIP_BUILDING_LIBRARY
 #define DETEXHIP_BUILDING_LIBRARY 1
@@ -37,6 +40,19 @@
 	} while (0)
 
 namespace detexhip {
+
+// A helper thread of the library's own (the duplex upload of host_tier.cpp, the per-shard workers of multi_device.cpp): started with every
+// signal blocked -- the host application's handlers run on the application's threads, not on one it does not know about -- and a refused
+// thread reported instead of thrown through the C ABI.
+template <class Thread, class F> inline bool start_helper_thread(Thread &t, F &&f) {
+	sigset_t all, old;
+	sigfillset(&all);
+	const bool masked = pthread_sigmask(SIG_SETMASK, &all, &old) == 0;
+	bool started = true;
+	try { t = Thread(std::forward<F>(f)); } catch (...) { started = false; }
+	if (masked) (void)pthread_sigmask(SIG_SETMASK, &old, nullptr);
+	return started;
+}
 
 // ---- what a launcher is handed --------------------------------------------------------------------------------------------
 struct Geometry {

@@ -594,18 +594,17 @@ struct TextureCall {
 		const int device = c.device;
 		// (band 0 goes up from THIS thread, on the main stream, while the helper -- whose first HIP call costs a few hundred microseconds -- starts)
 		std::thread uploader;
-		try {
-			uploader = std::thread([&, device]() {
-				hipError_t e = hipSetDevice(device);
-				for (int b = 1; b < B && e == hipSuccess; b++) {
-					const size_t r0 = row_of(b), r1 = row_of(b + 1);
-					e = hipMemcpyAsync(d_in + r0 * in_row, src + r0 * in_row, (r1 - r0) * in_row, hipMemcpyHostToDevice, c.stream_up);
-					if (e == hipSuccess) e = hipEventRecord(c.ev_up[b], c.stream_up);
-					if (e == hipSuccess) uploaded.store(b + 1, std::memory_order_release);
-				}
-				if (e != hipSuccess) { up_error = e; uploaded.store(-1, std::memory_order_release); }
-			});
-		} catch (...) {		// no thread to be had: nothing has been launched yet, the serial path takes the call
+		const bool started = start_helper_thread(uploader, [&, device]() {
+			hipError_t e = hipSetDevice(device);
+			for (int b = 1; b < B && e == hipSuccess; b++) {
+				const size_t r0 = row_of(b), r1 = row_of(b + 1);
+				e = hipMemcpyAsync(d_in + r0 * in_row, src + r0 * in_row, (r1 - r0) * in_row, hipMemcpyHostToDevice, c.stream_up);
+				if (e == hipSuccess) e = hipEventRecord(c.ev_up[b], c.stream_up);
+				if (e == hipSuccess) uploaded.store(b + 1, std::memory_order_release);
+			}
+			if (e != hipSuccess) { up_error = e; uploaded.store(-1, std::memory_order_release); }
+		});
+		if (!started) {		// no thread to be had: nothing has been launched yet, the serial path takes the call
 			c.dirty = false;
 			return kNotTaken;
 		}

@@ -281,9 +281,12 @@ extern "C" int detexhipDecompressTextureLinearMultiDeviceHost(uint32_t texture_f
 	};
 	if (n_shards == 1) run(0);
 	else {
+		// (one worker per shard, signals blocked in them; a shard whose thread the system refuses is done by the calling thread itself, after the others were started)
 		std::thread workers[64];
-		for (int g = 0; g < n_shards; g++) workers[g] = std::thread(run, g);
-		for (int g = 0; g < n_shards; g++) workers[g].join();
+		bool inline_shard[64] = {};
+		for (int g = 0; g < n_shards; g++) inline_shard[g] = !start_helper_thread(workers[g], [&run, g]() { run(g); });
+		for (int g = 0; g < n_shards; g++) if (inline_shard[g]) run(g);
+		for (int g = 0; g < n_shards; g++) if (workers[g].joinable()) workers[g].join();
 	}
 	if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	if (prev >= 0) (void)hipSetDevice(prev);
