@@ -5,7 +5,8 @@ then), a stream biased towards repeated blocks one time in three, decoded linear
 random epilogue target), block-major and through the per-block API with a random mode mask (device pointers, and a random count
 of the blocks through the batched host-pointer entry detexhipDecompressBlocks) -- and, for textures of up to 1024
 blocks, through the HOST-POINTER entry points twice in a row (the second call is answered by the resident kernel) plus two one-block
-leaf calls with a random mode mask -- each against the CPU oracle, bit for bit.  Test infrastructure only."""
+leaf calls with a random mode mask -- each against the CPU oracle, bit for bit; and every 29th seed one larger texture through the
+host-pointer tier's banded / staged / duplex paths against the device tier (_large_host_call).  Test infrastructure only."""
 import numpy as np
 
 from detex_amd import formats as F
@@ -100,4 +101,42 @@ def run_seed(seed, oracle, binding, torch):
                 if ok_1:
                     assert np.array_equal(got_1, want_b[k]), ("host block", hex(mask)) + where
             cases += 4
+    cases += _large_host_call(seed, rng, api, binding, torch)
     return cases
+
+
+# The host-pointer tier's larger paths (host_tier.cpp): every 29th seed a texture of the pinned exchange's banded range or of the staged path
+# (status word in pinned memory / in device memory), every 499th one with 32+ MiB of blocks (uploaded beside its download by the library's
+# helper thread) -- against the DEVICE tier on the same blocks (which the rest of this file holds against the oracle), either layout.
+LARGE_GEOMETRIES = [(512, 512), (724, 640), (1024, 1024), (2048, 1024), (2048, 2052), (1001, 513), (4096, 1028)]
+
+
+def _large_host_call(seed, rng, api, binding, torch):
+    if seed % 29 != 0:
+        return 0
+    duplex = seed % 499 == 0
+    names = ["BC1", "BC3", "BPTC", "RGTC2", "ETC2_EAC", "BPTC_FLOAT", "EAC_R11"]
+    fmt = F.BY_NAME[names[int(rng.integers(0, len(names)))]]
+    if duplex:
+        W, H = 8192, 4 * int(rng.integers(1024, 1100))
+        if fmt.block_bytes == 8:
+            H *= 2                                                     # 32+ MiB of blocks for the 8-byte formats too
+    else:
+        W, H = LARGE_GEOMETRIES[int(rng.integers(0, len(LARGE_GEOMETRIES)))]
+    wb, hb = (W + 3) // 4, (H + 3) // 4
+    data = ol.stream_u(fmt, wb * hb, seed=int(rng.integers(1, 1 << 40)))
+    if rng.integers(0, 2) == 0 and fmt.name == "BPTC":
+        data = data.copy().reshape(-1, 16); data[:, 0] |= 1; data = data.reshape(-1)      # all blocks valid: the result is then true
+    dev = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tiled = W % 4 == 0 and H % 4 == 0 and rng.integers(0, 3) == 0
+    if tiled:
+        want = binding.decompress_tiled_device(fmt, dev, wb, hb, status=status)
+    else:
+        want = binding.decompress_linear_device(fmt, dev, W, H, status=status)
+    torch.cuda.synchronize()
+    ok_h, got = api.tiled(fmt, data, wb, hb) if tiled else api.linear(fmt, data, W, H)
+    where = (fmt.name, W, H, seed, "tiled" if tiled else "linear", "duplex" if duplex else "staged")
+    assert np.array_equal(got, want.cpu().numpy()), ("large host call",) + where
+    assert ok_h == bool(status.item() == 0), ("large host call ok",) + where
+    return 1
