@@ -293,6 +293,10 @@ extern "C" int detexhipDecompressLevelsLinearDevice(uint32_t texture_format, con
 			detexSetErrorMessage("%s: bad geometry in level %d", who, l);
 			return 1;
 		}
+		if (reinterpret_cast<uintptr_t>(s.d_blocks) % detexGetCompressedBlockSize(texture_format) != 0) {	// (one 8 / 16-byte load per block, as in the one-texture entry)
+			detexSetErrorMessage("%s: d_blocks of level %d must be %d-byte aligned", who, l, (int)detexGetCompressedBlockSize(texture_format));
+			return 1;
+		}
 		LevelDesc &d = a.table.level[l];
 		d.blocks = s.d_blocks; d.pixels = static_cast<uint8_t *>(s.d_pixels); d.pitch = s.pitch_bytes;
 		d.width_in_blocks = (uint32_t)s.width_in_blocks; d.n_blocks = (uint32_t)(s.width_in_blocks * s.height_in_blocks);

@@ -191,6 +191,24 @@ bool heal_if_dirty() {
 // context_ready() + heal_if_dirty(): what every entry point of this file calls first
 bool context_usable() { return context_ready() && heal_if_dirty(); }
 
+// A call that fails after it has launched something returns with the context still `dirty` -- and, on the staged paths, possibly with copies
+// out of the caller's blocks or into the caller's pixel buffer still queued (memory the CALLER pinned makes the runtime's copies truly
+// asynchronous; with pageable memory they have ended when the call that asked for them returns).  Nothing of this library's may touch the
+// caller's memory once the call has returned: every entry point that hands caller memory to the runtime holds one of these, declared
+// after its DeviceScope.  (The device words stay as they are: the next call's heal_if_dirty puts them back to zero.)
+struct DrainOnFailure {
+	ThreadContext &c;
+	explicit DrainOnFailure(ThreadContext &context) : c(context) {}
+	DrainOnFailure(const DrainOnFailure &) = delete;
+	DrainOnFailure &operator=(const DrainOnFailure &) = delete;
+	~DrainOnFailure() {
+		if (!c.ready || !c.dirty) return;
+		if (c.stream_up) (void)hipStreamSynchronize(c.stream_up);
+		(void)hipStreamSynchronize(c.stream);
+		(void)hipGetLastError();
+	}
+};
+
 bool reserve(void **buf, size_t *cap, size_t need) {
 	if (need <= *cap) return true;
 	if (*buf) HIP_TRY(hipFree(*buf), "hipFree");
@@ -649,6 +667,7 @@ struct TextureCall {
 		uint8_t *d_out = static_cast<uint8_t *>(c.d_out);
 		const uint8_t *d_in;
 		auto try_hip = [](hipError_t e, const char *what) { if (e != hipSuccess) detexSetErrorMessage("libdetexhip: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
+		c.dirty = true;		// (from the first thing handed to the runtime on)
 		if (pinned_in) {
 			memcpy(x.h_base + x.in_off, texture->data, in_bytes);
 			d_in = x.d_base + x.in_off;
@@ -665,7 +684,6 @@ struct TextureCall {
 		volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(x.h_base + 16);		// (header of the exchange buffer: [0] status of the direct path, [8] its completion word)
 		uint32_t *d_status = pinned_status ? reinterpret_cast<uint32_t *>(x.d_base + 16) : c.d_status + kStagedStatusWord;
 		*h_status = pinned_status ? 0u : 0xFFFFFFFFu;
-		c.dirty = true;
 		const int rc = tiled ? detexhipDecompressTextureTiledDevice(texture->format, d_in, (int)wb, (int)hb, d_out, pixel_format, c.stream, d_status)
 			: detexhipDecompressTextureLinearDevice(texture->format, d_in, (int)width, (int)height, (int)wb, (int)hb, d_out, width * px, pixel_format, c.stream, d_status);
 		if (rc != 0) return kFalse;
@@ -722,6 +740,7 @@ static bool decompress_texture(const detexTexture *texture, uint8_t *pixel_buffe
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
+	DrainOnFailure drain(c);
 	const size_t bs = detexGetCompressedBlockSize(texture->format);
 	TextureCall call{ c, f, texture, pixel_buffer, pixel_format, tiled, px, wb, hb, width, height, bs, wb * hb * bs, out_bytes,
 		// The reference writes only the pixels its block grid covers and the image contains (texture.c:116-136): when the
@@ -757,6 +776,7 @@ extern "C" bool detexhipDecompressTexturesLinear(const detexTexture *const *text
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
+	DrainOnFailure drain(c);
 	const size_t bs = detexGetCompressedBlockSize(format);
 	size_t in_off[kMaxLevels], out_off[kMaxLevels], in_total = 0, out_total = 0;
 	for (int l = 0; l < n_textures; l++) {
@@ -822,6 +842,7 @@ extern "C" bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_t 
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
+	DrainOnFailure drain(c);
 	(void)c.service.wanted(nullptr, -1);		// not a call for the resident kernel: ends a row of small calls
 	const size_t in_bytes = n_blocks * bs, out_bytes = n_blocks * out_per_block;
 	const uint32_t decode_flags = (flags & 0x3FFFFFFFu) | current_spec_flags();
@@ -876,11 +897,12 @@ extern "C" bool detexhipModeHistogram(uint32_t texture_format, const uint8_t *bl
 	ThreadContext &c = t_ctx;
 	DeviceScope scope(c.device);
 	if (!scope.ok) return false;
+	DrainOnFailure drain(c);
 	const size_t nbytes = n_blocks * detexGetCompressedBlockSize(texture_format);
 	if (!reserve(&c.d_in, &c.in_cap, nbytes ? nbytes : 256)) return false;
+	c.dirty = true;
 	if (nbytes) HIP_TRY(hipMemcpyAsync(c.d_in, blocks, nbytes, hipMemcpyHostToDevice, c.stream), "hipMemcpyAsync(H2D)");
 	uint32_t *d_hist = c.d_status;		// words 0 .. kStatusHistogramBins - 1 of the status allocation, zeroed again below (the words are zero between calls)
-	c.dirty = true;
 	if (detexhipModeHistogramDevice(texture_format, c.d_in, n_blocks, d_hist, c.stream) != 0) return false;
 	HIP_TRY(hipMemcpyAsync(histogram, d_hist, kStatusHistogramBins * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream), "hipMemcpyAsync(D2H)");
 	HIP_TRY(hipMemsetAsync(d_hist, 0, kStatusHistogramBins * sizeof(uint32_t), c.stream), "hipMemsetAsync");

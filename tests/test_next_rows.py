@@ -224,6 +224,10 @@ def test_mip_chain_one_launch(name, pf, torch_cuda, hiplib, oracle):
         assert np.array_equal(got[:w * h * tpx], want), (name, i, w, h)
         assert (got[w * h * tpx:] == 0xA5).all()
     assert bool(status.item() == 0) == all_ok
+    # a level whose blocks are not aligned to the block size is refused like the one-texture entry refuses it (a block is ONE 8 / 16-byte load)
+    arr[1].d_blocks = d_in[1].data_ptr() + 4
+    assert lib.detexhipDecompressLevelsLinearDevice(fmt.texture_format, arr, len(levels), pf, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), status.data_ptr()) == 1
+    assert "level 1" in binding.last_error() and "aligned" in binding.last_error()
     # host tier: the same chain through detexTexture structs, one call
     texs = [ol.DetexTexture(fmt.texture_format, ol._ptr(d), w, h, (w + 3) // 4, (h + 3) // 4) for w, h, d in levels]
     outs = [np.zeros(w * h * tpx, np.uint8) for w, h, _ in levels]
