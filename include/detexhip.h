@@ -186,7 +186,7 @@ DETEXHIP_API bool detexhipDecompressBlocks(uint32_t texture_format, const uint8_
  * rules as detexhipDecompressTextureLinearDevice (clipping, fast/clipped store path per level).
  * At most 16 levels per call (a full chain of a 32768^2 texture). */
 typedef struct {
-	const void *d_blocks;		/* width_in_blocks * height_in_blocks blocks, row-major */
+	const void *d_blocks;		/* width_in_blocks * height_in_blocks blocks, row-major; aligned to the block size (8 / 16 bytes), as for the one-texture entry */
 	void *d_pixels;
 	size_t pitch_bytes;
 	int width, height, width_in_blocks, height_in_blocks;
