@@ -62,6 +62,10 @@ import os
 import sys
 import time
 
+# (multi-process GPU work on this pool needs dmabuf IPC: the driver's environment exports this already; kept here, before the HIP runtime starts,
+# for a launcher that hands the ranks a scrubbed environment -- without it RCCL fails with `hipIpcGetMemHandle: invalid argument`)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
